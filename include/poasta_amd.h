@@ -1,0 +1,145 @@
+/* poasta_amd — C ABI of the MI355X (gfx950) gap-affine POA alignment engine.
+ *
+ * Drop-in boundary: everything behind `poasta::aligner::PoastaAligner::{align,
+ * align_with_existing_bubbles, align_no_pruning}` (/root/reference/src/aligner/mod.rs:69-145),
+ * i.e. `astar_alignment` (src/aligner/astar.rs:108-226) + the score-based backtrace
+ * (src/aligner/scoring/gap_affine.rs:550-657, :804-915), for the gap-affine cost model
+ * (`GapAffine`, gap_affine.rs:20-30) in Global mode with query offsets of type u32
+ * (the only instantiation the reference binaries use: src/bin/poasta.rs:214, src/bin/lasagna.rs:125).
+ *
+ * The host keeps the graph (`POAGraph`), builds it, mutates it and does all I/O.  It hands the
+ * library a flattened view of the `AlignableRefGraph` trait (src/graphs/mod.rs:23-53) and a batch of
+ * queries (the `lasagna align` shape, src/bin/lasagna.rs:184-276: N reads x 1 immutable graph).
+ *
+ * Plain C: pointers and sizes only.  All functions return POA_OK (0) or a negative POA_ERR_* code;
+ * nothing aborts or throws across this boundary.  INTEGRATION.md shows the Rust `extern "C"` block
+ * and the ~30-line shim inside `PoastaAligner::align_internal`.
+ */
+#ifndef POASTA_AMD_H
+#define POASTA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POA_NONE 0xFFFFFFFFu /* AlignedPair{rpos|qpos: None} (src/aligner/alignment.rs:4-13) */
+#define POA_SCORE_UNVISITED 0xFFFFFFFFu /* Score::Unvisited (src/aligner/scoring/mod.rs:64-70) */
+
+/* return codes */
+#define POA_OK 0
+#define POA_ERR_INVALID_ARG (-1)
+#define POA_ERR_NOT_A_DAG (-2)      /* cycle, unreachable node, start with predecessors, end with successors */
+#define POA_ERR_NO_DEVICE (-3)      /* no usable gfx950 device: the HIP path never falls back to the CPU */
+#define POA_ERR_HIP (-4)            /* a HIP runtime call failed; see poa_last_error() */
+#define POA_ERR_CAPACITY (-5)       /* pair_capacity too small; pair_off[n] holds the needed total */
+#define POA_ERR_OUT_OF_MEMORY (-6)
+#define POA_ERR_UNSUPPORTED (-7)
+
+/* per-query flags (poa_align_batch `flags`).
+ * Scores are exact whenever START_QUIRK and SHORT_QUERY are clear.  The alignment is the
+ * reference's, bit for bit, whenever the word is 0: the optimal alignment is then unique in the
+ * reference's own alignment graph, so every search order yields it. */
+#define POA_FLAG_AMBIGUOUS 0x01u    /* >1 co-optimal alignment: the reference's pick depends on its search order */
+#define POA_FLAG_START_QUIRK 0x02u  /* path uses an edge the reference's offset-0 special case may hide (dfa.rs:146-167) */
+#define POA_FLAG_REF_PANIC 0x04u    /* the reference would panic on this input (u32 wrap in mod.rs:144-152) */
+#define POA_FLAG_SHORT_QUERY 0x08u  /* len <= 1: reference special cases (gap_affine.rs:808-824) */
+#define POA_FLAG_TRUNCATED 0x10u    /* backtrace ended before the start node (as the reference's would) */
+#define POA_FLAG_EMPTY_GRAPH 0x20u  /* no real nodes: PoastaAligner::align shortcut (mod.rs:124-142), score 4*len */
+
+/* GapAffine (gap_affine.rs:20-24).  NB the Rust constructor order is (mismatch, extend, open). */
+typedef struct poa_costs {
+    uint8_t mismatch;
+    uint8_t gap_open;
+    uint8_t gap_extend;
+    uint8_t reserved;
+} poa_costs_t;
+
+/* AlignedPair (alignment.rs:4-13): rpos = node index of the host graph, qpos = 0-based query position */
+typedef struct poa_aln_pair {
+    uint32_t rpos;
+    uint32_t qpos;
+} poa_aln_pair_t;
+
+/* Counters returned per call — the analogue of AstarResult::{num_queued,num_visited,num_pruned}
+ * (astar.rs:86-89) for a dense pass, plus HIP-event timings taken on the launch stream. */
+typedef struct poa_stats {
+    uint64_t cells;            /* sum over queries of rows * (len + 1) */
+    uint64_t bases;            /* sum of query lengths */
+    uint64_t plane_bytes;      /* bytes of M/I/D score planes written */
+    uint32_t n_queries;
+    uint32_t n_chunks;         /* query chunks processed (workspace reuse) */
+    uint32_t n_forward_launches;
+    uint32_t n_flagged;        /* queries with flags != 0 */
+    float ms_forward;          /* sum of forward-kernel durations (HIP events) */
+    float ms_traceback;        /* sum of traceback + compaction kernel durations */
+    float ms_h2d;              /* query upload (poa_align_batch only) */
+    float ms_d2h;              /* result download (poa_align_batch / poa_batch_fetch) */
+    float ms_total;            /* first launch -> last kernel end */
+    uint32_t reserved;
+} poa_stats_t;
+
+typedef struct poa_graph poa_graph_t;
+typedef struct poa_batch poa_batch_t;
+
+/* ---- library --------------------------------------------------------------------------- */
+const char* poa_version(void);
+const char* poa_last_error(void);     /* thread-local description of the last failure */
+int poa_device_count(void);           /* number of visible HIP devices (0 if none) */
+
+/* ---- graph: the flattened AlignableRefGraph --------------------------------------------- */
+/* Built once per graph by iterating the trait in the host (graphs/mod.rs:23-53):
+ *   n          node_count_with_start_and_end()
+ *   start,end  start_node(), end_node()
+ *   symbol[n]  get_symbol_char() as u8 ('#' start, '$' end: graphs/poa.rs:102-103)
+ *   succ_off[n+1], succ[]   successors(v) in ITERATION ORDER
+ *   pred_off[n+1], pred[]   predecessors(v) in ITERATION ORDER (decides traceback ties,
+ *                           gap_affine.rs:591,:617,:627)
+ * The end node equals every query symbol (POAGraph::is_symbol_equal, graphs/poa.rs:463-465).
+ * The library copies everything; the caller keeps ownership of its arrays. */
+int poa_graph_create(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol,
+                     const uint32_t* succ_off, const uint32_t* succ,
+                     const uint32_t* pred_off, const uint32_t* pred, poa_graph_t** out);
+void poa_graph_destroy(poa_graph_t* g);
+uint32_t poa_graph_rows(const poa_graph_t* g);           /* == n */
+/* row (topological rank used for the score planes) of every node; rank[n] */
+int poa_graph_node_rows(const poa_graph_t* g, uint32_t* rank);
+
+/* ---- one-shot batch alignment (host buffers in, host buffers out) ------------------------ */
+/* Replaces, for a batch of queries against one graph, what the reference does per query in
+ * `align_sequence` (src/bin/lasagna.rs:112-138) / `perform_alignment` (src/bin/poasta.rs:214).
+ *   qseq,qoff[n+1]  concatenated queries
+ *   score[n]        AstarResult::score
+ *   pairs, pair_off[n+1], pair_capacity   AstarResult::alignment of query i =
+ *                   pairs[pair_off[i] .. pair_off[i+1]); capacity sum(len_i + n_nodes) always suffices
+ *   flags[n]        POA_FLAG_* (may be NULL)
+ *   stats           may be NULL
+ *   device          HIP device ordinal */
+int poa_align_batch(const poa_graph_t* g, const poa_costs_t* costs, uint32_t n_queries,
+                    const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
+                    poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
+                    uint32_t* flags, poa_stats_t* stats, int device);
+
+/* ---- resident batch (queries and results stay in HBM; used by the multi-GPU driver) ------ */
+/* poa_batch_create uploads graph + queries to `device` and sizes the score-plane workspace
+ * (workspace_bytes = 0: pick from free memory).  poa_batch_run launches forward + traceback on
+ * `stream` (a hipStream_t, NULL = default stream) and returns without synchronising.
+ * poa_batch_fetch synchronises the stream and copies results to the host. */
+int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const uint8_t* qseq,
+                     const uint64_t* qoff, uint64_t workspace_bytes, poa_batch_t** out);
+int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream);
+int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
+                    uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats);
+/* device pointers of the results of the last run (valid until the next run / destroy):
+ * score u32[n], flags u32[n], pair_off u64[n+1], pairs poa_aln_pair_t[pair_off[n]] */
+int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** pair_off, void** pairs);
+/* debugging / parity: copy the M, I, D score planes of query i (rows x (len+1), row = topological
+ * rank, see poa_graph_node_rows) — only valid if the query's chunk was the last one run */
+int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t* i, uint32_t* d);
+void poa_batch_destroy(poa_batch_t* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POASTA_AMD_H */

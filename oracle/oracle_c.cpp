@@ -1,0 +1,300 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+// C entry points (ctypes) over the CPU restatement in astar.hpp / dense.hpp.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "astar.hpp"
+#include "bubbles.hpp"
+#include "dense.hpp"
+#include "graph.hpp"
+
+using namespace poa_oracle;
+
+namespace {
+struct GraphHandle {
+    Graph g;
+    std::unique_ptr<BubbleIndex> bubbles;  // lazily built; invalidated on mutation
+    const BubbleIndex& bi() {
+        if (!bubbles) bubbles.reset(new BubbleIndex(g));
+        return *bubbles;
+    }
+};
+thread_local std::string g_last_error;
+}  // namespace
+
+extern "C" {
+
+const char* oracle_last_error() { return g_last_error.c_str(); }
+
+void* oracle_graph_from_csr(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sym,
+                            const uint32_t* succ_off, const uint32_t* succ, const uint32_t* pred_off,
+                            const uint32_t* pred, int end_matches_all) {
+    try {
+        auto* h = new GraphHandle;
+        h->g = Graph::from_csr(n, start, end, sym, succ_off, succ, pred_off, pred, end_matches_all != 0);
+        return h;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return nullptr; }
+}
+void* oracle_graph_new_poa() { auto* h = new GraphHandle; h->g = Graph::new_poa(); return h; }
+void* oracle_graph_mock(int which) {
+    auto* h = new GraphHandle;
+    h->g = which == 1 ? create_test_graph1() : create_test_graph2();
+    return h;
+}
+// generic mock graph from an edge list, edges added in the given order (petgraph add_edge semantics)
+void* oracle_graph_mock_edges(uint32_t n, const uint32_t* edges, uint32_t n_edges, const uint8_t* sym) {
+    try {
+        auto* h = new GraphHandle;
+        h->g = Graph::new_mock(n);
+        for (uint32_t i = 0; i < n_edges; ++i) h->g.raw_add_edge(edges[2 * i], edges[2 * i + 1]);
+        if (sym) h->g.symbol.assign(sym, sym + n);
+        h->g.compute_topo();
+        return h;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return nullptr; }
+}
+void oracle_graph_free(void* p) { delete (GraphHandle*)p; }
+void oracle_graph_set_symbols(void* p, const uint8_t* sym) {
+    auto* h = (GraphHandle*)p;
+    h->g.symbol.assign(sym, sym + h->g.symbol.size());
+}
+uint32_t oracle_graph_n(void* p) { return (uint32_t)((GraphHandle*)p)->g.symbol.size(); }
+uint32_t oracle_graph_start(void* p) { return ((GraphHandle*)p)->g.start; }
+uint32_t oracle_graph_end(void* p) { return ((GraphHandle*)p)->g.end; }
+uint32_t oracle_graph_n_edges(void* p) {
+    size_t e = 0;
+    for (auto& s : ((GraphHandle*)p)->g.succ) e += s.size();
+    return (uint32_t)e;
+}
+// CSR in trait-iteration order + node ranks (get_node_ordering)
+void oracle_graph_export(void* p, uint8_t* sym, uint32_t* succ_off, uint32_t* succ, uint32_t* pred_off,
+                         uint32_t* pred, uint32_t* rank) {
+    Graph& g = ((GraphHandle*)p)->g;
+    uint32_t n = (uint32_t)g.symbol.size();
+    std::memcpy(sym, g.symbol.data(), n);
+    uint32_t so = 0, po = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+        succ_off[v] = so; pred_off[v] = po;
+        for (uint32_t s : g.succ[v]) succ[so++] = s;
+        for (uint32_t q : g.pred[v]) pred[po++] = q;
+    }
+    succ_off[n] = so; pred_off[n] = po;
+    auto r = g.node_ranks();
+    std::memcpy(rank, r.data(), n * sizeof(uint32_t));
+}
+// POAGraph::add_alignment_with_weights (poa.rs:171-321); n_pairs < 0 == None
+int oracle_poa_add_alignment(void* p, const char* name, const uint8_t* seq, uint64_t len, const uint32_t* pairs,
+                             int64_t n_pairs) {
+    auto* h = (GraphHandle*)p;
+    h->bubbles.reset();
+    try {
+        if (n_pairs < 0) return h->g.add_alignment(name ? name : "", seq, len, nullptr);
+        std::vector<AlignedPair> aln((size_t)n_pairs);
+        for (int64_t i = 0; i < n_pairs; ++i) aln[i] = {pairs[2 * i], pairs[2 * i + 1]};
+        return h->g.add_alignment(name ? name : "", seq, len, &aln);
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+uint32_t oracle_poa_n_sequences(void* p) { return (uint32_t)((GraphHandle*)p)->g.n_sequences; }
+uint32_t oracle_poa_seq_start(void* p, uint32_t i) { return ((GraphHandle*)p)->g.seq_start_nodes[i]; }
+// aligned_nodes of one node (poa.rs:374-376); returns count, fills up to cap
+uint32_t oracle_poa_aligned_nodes(void* p, uint32_t node, uint32_t* out, uint32_t cap) {
+    auto& a = ((GraphHandle*)p)->g.aligned_nodes[node];
+    for (uint32_t i = 0; i < a.size() && i < cap; ++i) out[i] = a[i];
+    return (uint32_t)a.size();
+}
+
+// ---- known-answer hooks ---------------------------------------------------
+uint64_t oracle_gap_cost(uint8_t m, uint8_t o, uint8_t e, int state, uint64_t len) {
+    Costs c{m, o, e};
+    return c.gap_cost((AlignState)state, len);
+}
+// rev_postorder_nodes (tools.rs:5); out has n entries, returns count
+uint32_t oracle_rev_postorder(void* p, uint32_t* out) {
+    auto v = rev_postorder_nodes(((GraphHandle*)p)->g);
+    std::memcpy(out, v.data(), v.size() * 4);
+    return (uint32_t)v.size();
+}
+// superbubbles (entrance, exit) in yield order; out has 2*n entries
+int oracle_superbubbles(void* p, uint32_t* out) {
+    try {
+        SuperbubbleFinder f(((GraphHandle*)p)->g);
+        auto v = f.find_all();
+        for (size_t i = 0; i < v.size(); ++i) { out[2 * i] = v[i].first; out[2 * i + 1] = v[i].second; }
+        return (int)v.size();
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+// bubble index: dist_to_end (min,max per node), node_bubble_map flattened as (exit,min,max) with offsets[n+1]
+int oracle_bubble_index(void* p, uint64_t* dist_min, uint64_t* dist_max, uint32_t* nbm_off, uint32_t* nbm_exit,
+                        uint64_t* nbm_min, uint64_t* nbm_max, uint32_t nbm_cap, uint8_t* is_entrance, uint8_t* is_exit) {
+    try {
+        auto* h = (GraphHandle*)p;
+        const BubbleIndex& b = h->bi();
+        uint32_t n = (uint32_t)h->g.symbol.size(), k = 0;
+        for (uint32_t v = 0; v < n; ++v) {
+            dist_min[v] = b.dist_to_end[v].first; dist_max[v] = b.dist_to_end[v].second;
+            is_entrance[v] = b.is_entrance_v[v]; is_exit[v] = b.is_exit_v[v];
+            nbm_off[v] = k;
+            for (auto& m : b.node_bubble_map[v]) {
+                if (k < nbm_cap) { nbm_exit[k] = m.bubble_exit; nbm_min[k] = m.min_dist_to_exit; nbm_max[k] = m.max_dist_to_exit; }
+                k++;
+            }
+        }
+        nbm_off[n] = k;
+        return (int)k;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+uint64_t oracle_heuristic_h(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, uint64_t seq_len, uint32_t node,
+                            uint32_t offset, int state) {
+    auto* h = (GraphHandle*)p;
+    Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, true);
+    a.seq_len = seq_len;
+    return a.h({node, offset}, (AlignState)state);
+}
+// first DFA event from (node, offset) on a fresh visited table (== DummyVisited that always
+// accepts, dfa.rs:351-401); force_prune mirrors DummyVisited::prune_next.
+// out: kind(0 none,1 RefGraphEnd,2 QueryEnd,3 Mismatch), parent node/off, child node/off, num_visited, num_pruned
+int oracle_dfa_first_event(void* p, const uint8_t* seq, uint64_t len, uint32_t node, uint32_t offset, int force_prune,
+                           uint64_t* out) {
+    try {
+        auto* h = (GraphHandle*)p;
+        Aligner a(h->g, h->bi(), Costs{4, 6, 2}, H_DIJKSTRA, true);
+        a.seq = seq; a.seq_len = len;
+        a.visited.init(h->g, a.ranks, len);
+        a.forced_prune = force_prune ? 1 : 0;
+        Aligner::DFA dfa(a, 0, {node, offset});
+        Aligner::DFA::Event ev = dfa.extend();
+        out[0] = ev.kind; out[1] = ev.parent.node; out[2] = ev.parent.offset; out[3] = ev.child.node;
+        out[4] = ev.child.offset; out[5] = dfa.num_visited; out[6] = dfa.num_pruned;
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+// LayeredQueue scripted access (queue.rs:109-136)
+void* oracle_queue_new() { return new LayeredQueue; }
+void oracle_queue_free(void* q) { delete (LayeredQueue*)q; }
+void oracle_queue_push(void* q, uint32_t value, uint64_t priority) {
+    ((LayeredQueue*)q)->queue({value, {0, 0}, ST_M}, priority);
+}
+int64_t oracle_queue_pop(void* q) {
+    QueuedItem it;
+    return ((LayeredQueue*)q)->pop(it) ? (int64_t)it.score : -1;
+}
+uint64_t oracle_queue_layers(void* q) { return ((LayeredQueue*)q)->layers.size(); }
+uint64_t oracle_queue_layer_min(void* q) { return ((LayeredQueue*)q)->layer_min; }
+uint64_t oracle_queue_layer_len(void* q, uint64_t ix) { return ((LayeredQueue*)q)->layers[ix].m.size(); }
+
+// ---- alignment --------------------------------------------------------------
+// status: 0 ok, 1 reference would panic (message in oracle_last_error), 2 pair capacity too small
+static int run_astar(GraphHandle* h, Aligner& a, const uint8_t* seq, uint64_t len, uint32_t* score, uint32_t* pairs,
+                     uint64_t cap, uint64_t* n_pairs, uint64_t* counters) {
+    try {
+        AstarResult r = a.align(seq, len);
+        *score = r.score;
+        *n_pairs = r.alignment.size();
+        if (counters) { counters[0] = r.num_queued; counters[1] = r.num_visited; counters[2] = r.num_pruned; }
+        if (r.alignment.size() > cap) return 2;
+        for (size_t i = 0; i < r.alignment.size(); ++i) { pairs[2 * i] = r.alignment[i].rpos; pairs[2 * i + 1] = r.alignment[i].qpos; }
+        return 0;
+    } catch (const RefPanic& ex) { g_last_error = ex.what(); *n_pairs = 0; *score = UNVISITED; return 1; }
+    (void)h;
+}
+
+int oracle_astar_align(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, const uint8_t* seq,
+                       uint64_t len, uint32_t* score, uint32_t* pairs, uint64_t cap, uint64_t* n_pairs,
+                       uint64_t* counters) {
+    auto* h = (GraphHandle*)p;
+    try {
+        Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        return run_astar(h, a, seq, len, score, pairs, cap, n_pairs, counters);
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+// lasagna-shaped batch (src/bin/lasagna.rs:246-268): n_threads workers, one aligner each,
+// shared immutable graph + bubble index.  pair_off[n+1] = capacity offsets into `pairs` (in pairs).
+int oracle_astar_batch(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, uint32_t n_queries,
+                       const uint8_t* qseq, const uint64_t* qoff, uint32_t* scores, uint32_t* pairs,
+                       const uint64_t* pair_off, uint64_t* n_pairs, uint64_t* counters /* [n][3] or null */,
+                       int32_t* status, int n_threads) {
+    auto* h = (GraphHandle*)p;
+    try {
+        const BubbleIndex& bi = h->bi();
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            Aligner a(h->g, bi, Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+            for (;;) {
+                uint32_t i = next.fetch_add(1);
+                if (i >= n_queries) break;
+                status[i] = run_astar(h, a, qseq + qoff[i], qoff[i + 1] - qoff[i], &scores[i],
+                                      pairs ? pairs + 2 * pair_off[i] : nullptr,
+                                      pairs ? pair_off[i + 1] - pair_off[i] : 0, &n_pairs[i],
+                                      counters ? counters + 3 * (size_t)i : nullptr);
+                if (!pairs && status[i] == 2) status[i] = 0;
+            }
+        };
+        if (n_threads <= 1) work();
+        else {
+            std::vector<std::thread> ts;
+            for (int t = 0; t < n_threads; ++t) ts.emplace_back(work);
+            for (auto& t : ts) t.join();
+        }
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+// Dense restatement (dense.hpp).  planes (M,I,D) optional: each rows*(len+1) u32, row = topological rank.
+int oracle_dense_align(void* p, uint8_t m, uint8_t o, uint8_t e, const uint8_t* seq, uint64_t len, uint32_t* score,
+                       uint32_t* pairs, uint64_t cap, uint64_t* n_pairs, uint32_t* flags, uint32_t* pm, uint32_t* pi,
+                       uint32_t* pd) {
+    auto* h = (GraphHandle*)p;
+    try {
+        DenseAligner a(h->g, Costs{m, o, e});
+        DenseResult r = a.align(seq, len, pm != nullptr);
+        *score = r.score; *flags = r.flags; *n_pairs = r.alignment.size();
+        if (pm) {
+            std::memcpy(pm, r.M.data(), r.M.size() * 4);
+            std::memcpy(pi, r.I.data(), r.I.size() * 4);
+            std::memcpy(pd, r.D.data(), r.D.size() * 4);
+        }
+        if (r.alignment.size() > cap) return 2;
+        for (size_t i = 0; i < r.alignment.size(); ++i) { pairs[2 * i] = r.alignment[i].rpos; pairs[2 * i + 1] = r.alignment[i].qpos; }
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+int oracle_dense_batch(void* p, uint8_t m, uint8_t o, uint8_t e, uint32_t n_queries, const uint8_t* qseq,
+                       const uint64_t* qoff, uint32_t* scores, uint32_t* pairs, const uint64_t* pair_off,
+                       uint64_t* n_pairs, uint32_t* flags, int n_threads) {
+    auto* h = (GraphHandle*)p;
+    try {
+        DenseAligner a(h->g, Costs{m, o, e});
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                uint32_t i = next.fetch_add(1);
+                if (i >= n_queries) break;
+                DenseResult r = a.align(qseq + qoff[i], qoff[i + 1] - qoff[i]);
+                scores[i] = r.score; flags[i] = r.flags; n_pairs[i] = r.alignment.size();
+                if (pairs) {
+                    uint64_t cap = pair_off[i + 1] - pair_off[i];
+                    for (size_t k = 0; k < r.alignment.size() && k < cap; ++k) {
+                        pairs[2 * (pair_off[i] + k)] = r.alignment[k].rpos;
+                        pairs[2 * (pair_off[i] + k) + 1] = r.alignment[k].qpos;
+                    }
+                }
+            }
+        };
+        if (n_threads <= 1) work();
+        else {
+            std::vector<std::thread> ts;
+            for (int t = 0; t < n_threads; ++t) ts.emplace_back(work);
+            for (auto& t : ts) t.join();
+        }
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+}  // extern "C"

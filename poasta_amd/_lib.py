@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI in include/poasta_amd.h (libpoasta_amd.so, built in-tree by hipcc).
+
+There is no fallback: if the shared library is missing or cannot be loaded the import of any compute
+entry point raises, and on a box without a HIP device every compute call returns POA_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpoasta_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+POA_OK = 0
+ERRORS = {-1: "POA_ERR_INVALID_ARG", -2: "POA_ERR_NOT_A_DAG", -3: "POA_ERR_NO_DEVICE", -4: "POA_ERR_HIP",
+          -5: "POA_ERR_CAPACITY", -6: "POA_ERR_OUT_OF_MEMORY", -7: "POA_ERR_UNSUPPORTED"}
+POA_NONE = 0xFFFFFFFF
+FLAG_AMBIGUOUS, FLAG_START_QUIRK, FLAG_REF_PANIC, FLAG_SHORT_QUERY, FLAG_TRUNCATED, FLAG_EMPTY_GRAPH = 1, 2, 4, 8, 16, 32
+
+# every symbol include/poasta_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = ["poa_version", "poa_last_error", "poa_device_count", "poa_graph_create", "poa_graph_destroy",
+           "poa_graph_rows", "poa_graph_node_rows", "poa_align_batch", "poa_batch_create", "poa_batch_run",
+           "poa_batch_fetch", "poa_batch_device_results", "poa_batch_fetch_planes", "poa_batch_destroy"]
+
+
+class PoaCosts(C.Structure):
+    _fields_ = [("mismatch", C.c_uint8), ("gap_open", C.c_uint8), ("gap_extend", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class PoaStats(C.Structure):
+    _fields_ = [("cells", C.c_uint64), ("bases", C.c_uint64), ("plane_bytes", C.c_uint64), ("n_queries", C.c_uint32),
+                ("n_chunks", C.c_uint32), ("n_forward_launches", C.c_uint32), ("n_flagged", C.c_uint32),
+                ("ms_forward", C.c_float), ("ms_traceback", C.c_float), ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),
+                ("ms_total", C.c_float), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class PoaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "POA_ERR"), code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP engine for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "poasta_amd.h")]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("poasta_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.poa_version.restype = C.c_char_p
+    L.poa_last_error.restype = C.c_char_p
+    L.poa_device_count.restype = C.c_int
+    L.poa_graph_create.restype = C.c_int
+    L.poa_graph_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.poa_graph_destroy.argtypes = [vp]
+    L.poa_graph_destroy.restype = None
+    L.poa_graph_rows.restype = C.c_uint32
+    L.poa_graph_rows.argtypes = [vp]
+    L.poa_graph_node_rows.restype = C.c_int
+    L.poa_graph_node_rows.argtypes = [vp, vp]
+    L.poa_align_batch.restype = C.c_int
+    L.poa_align_batch.argtypes = [vp, C.POINTER(PoaCosts), C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp,
+                                  C.POINTER(PoaStats), C.c_int]
+    L.poa_batch_create.restype = C.c_int
+    L.poa_batch_create.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.poa_batch_run.restype = C.c_int
+    L.poa_batch_run.argtypes = [vp, C.POINTER(PoaCosts), vp]
+    L.poa_batch_fetch.restype = C.c_int
+    L.poa_batch_fetch.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.POINTER(PoaStats)]
+    L.poa_batch_device_results.restype = C.c_int
+    L.poa_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.poa_batch_fetch_planes.restype = C.c_int
+    L.poa_batch_fetch_planes.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    L.poa_batch_destroy.argtypes = [vp]
+    L.poa_batch_destroy.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != POA_OK:
+        raise PoaError(rc, lib().poa_last_error().decode(errors="replace"))

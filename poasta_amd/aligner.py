@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's aligner entry point, running on the gfx950 engine.
+
+Mirrors `poasta::aligner::PoastaAligner` (/root/reference/src/aligner/mod.rs:40-146) and the types a
+caller touches: `GapAffine` (scoring/gap_affine.rs:20-30), the `AlignmentConfig` bindings
+`AffineMinGapCost` / `AffineDijkstra` (config.rs:49,:104), `AlignmentType` (scoring/mod.rs:50-62),
+`AstarResult` (astar.rs:81-90) and `AlignedPair` (alignment.rs:4-13).  Same names, same argument
+meaning; errors are exceptions where the reference panics.
+
+What differs, by design: a call computes the full M/I/D score planes on the GPU instead of searching
+them with A*; `AstarResult.flags` reports when the reference's own search order could have picked
+a different co-optimal alignment (0 = provably the reference's alignment).
+`align_batch` is the data-parallel shape of `lasagna align` (src/bin/lasagna.rs:184-276).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .graph import FlatGraph, pack_queries
+
+
+class GapAffine:
+    """`GapAffine::new(cost_mismatch, cost_gap_extend, cost_gap_open)` — NB the argument order
+    (scoring/gap_affine.rs:27)."""
+
+    def __init__(self, cost_mismatch, cost_gap_extend, cost_gap_open):
+        for v in (cost_mismatch, cost_gap_extend, cost_gap_open):
+            if not 0 <= int(v) <= 255:
+                raise ValueError("GapAffine costs are u8")
+        self.cost_mismatch, self.cost_gap_extend, self.cost_gap_open = int(cost_mismatch), int(cost_gap_extend), int(cost_gap_open)
+
+    def mismatch(self):
+        return self.cost_mismatch
+
+    def gap_open(self):
+        return self.cost_gap_open
+
+    def gap_extend(self):
+        return self.cost_gap_extend
+
+    def gap_cost(self, in_gap_state, length):
+        """gap_affine.rs:68-80; in_gap_state False == AlignState::Match."""
+        if length == 0:
+            return 0
+        return (0 if in_gap_state else self.cost_gap_open) + length * self.cost_gap_extend
+
+    def _c(self):
+        return _lib.PoaCosts(self.cost_mismatch, self.cost_gap_open, self.cost_gap_extend, 0)
+
+
+class AlignmentType:
+    """scoring/mod.rs:50-62.  Only Global is implemented on the GPU path (what `lasagna` hard-codes,
+    src/bin/lasagna.rs:256)."""
+    Global = "global"
+
+
+class AffineMinGapCost:
+    """config.rs:104 — the default config of both reference CLIs.  The heuristic only fixes the
+    reference's search order; the dense GPU pass has none."""
+
+    def __init__(self, costs):
+        self.costs = costs
+
+
+class AffineDijkstra(AffineMinGapCost):
+    """config.rs:49."""
+
+
+class AlignedPair:
+    __slots__ = ("rpos", "qpos")
+
+    def __init__(self, rpos, qpos):
+        self.rpos, self.qpos = rpos, qpos
+
+    def is_aligned(self):
+        return self.rpos is not None and self.qpos is not None
+
+    def is_indel(self):
+        return not self.is_aligned()
+
+    def __eq__(self, o):
+        return (self.rpos, self.qpos) == (o.rpos, o.qpos)
+
+    def __repr__(self):
+        return "AlignedPair(rpos=%r, qpos=%r)" % (self.rpos, self.qpos)
+
+
+class AstarResult:
+    """astar.rs:81-90.  `num_*` search counters have no meaning for a dense pass and are 0;
+    `cells` = rows x (len + 1) computed for this query."""
+
+    def __init__(self, score, alignment, flags=0, cells=0):
+        self.score, self.alignment, self.flags, self.cells = score, alignment, flags, cells
+        self.num_queued = self.num_visited = self.num_pruned = 0
+
+    def pairs(self):
+        return [(p.rpos, p.qpos) for p in self.alignment]
+
+
+class BatchResult:
+    """Struct-of-arrays result of `align_batch`."""
+
+    def __init__(self, score, pairs, pair_off, flags, stats):
+        self.score, self.pairs, self.pair_off, self.flags, self.stats = score, pairs, pair_off, flags, stats
+
+    def __len__(self):
+        return len(self.score)
+
+    def alignment(self, i):
+        """[(rpos|None, qpos|None), ...] of query i."""
+        a = self.pairs[int(self.pair_off[i]):int(self.pair_off[i + 1])]
+        return [(None if r == _lib.POA_NONE else int(r), None if q == _lib.POA_NONE else int(q)) for r, q in a.tolist()]
+
+    def raw_alignment(self, i):
+        return [tuple(x) for x in self.pairs[int(self.pair_off[i]):int(self.pair_off[i + 1])].tolist()]
+
+    def result(self, i):
+        return AstarResult(int(self.score[i]), [AlignedPair(r, q) for r, q in self.alignment(i)], int(self.flags[i]))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceGraph:
+    """Owns a `poa_graph_t` (the flattened AlignableRefGraph)."""
+
+    def __init__(self, graph):
+        if not isinstance(graph, FlatGraph):
+            graph = FlatGraph.from_dict(graph)
+        self.graph = graph
+        h = C.c_void_p()
+        _lib.check(_lib.lib().poa_graph_create(graph.n, graph.start, graph.end, _p(graph.symbol), _p(graph.succ_off),
+                                               _p(graph.succ), _p(graph.pred_off), _p(graph.pred), C.byref(h)))
+        self.handle = h
+
+    def node_rows(self):
+        r = np.zeros(self.graph.n, np.uint32)
+        _lib.check(_lib.lib().poa_graph_node_rows(self.handle, _p(r)))
+        return r
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().poa_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _device_graph(graph):
+    if isinstance(graph, DeviceGraph):
+        return graph
+    dg = getattr(graph, "_device_graph", None)
+    if dg is None:
+        dg = DeviceGraph(graph)
+        try:
+            graph._device_graph = dg
+        except Exception:
+            pass
+    return dg
+
+
+class ResidentBatch:
+    """Queries + results resident in HBM (`poa_batch_*`): create once, run many times."""
+
+    def __init__(self, graph, qseq, qoff, device=0, workspace_bytes=0):
+        self.dg = _device_graph(graph)
+        self.qseq = np.ascontiguousarray(qseq, np.uint8)
+        self.qoff = np.ascontiguousarray(qoff, np.uint64)
+        self.n = len(self.qoff) - 1
+        h = C.c_void_p()
+        _lib.check(_lib.lib().poa_batch_create(self.dg.handle, device, self.n, _p(self.qseq), _p(self.qoff),
+                                               int(workspace_bytes), C.byref(h)))
+        self.handle = h
+        self.pair_capacity = int(self.qoff[-1]) + self.n * self.dg.graph.n
+
+    def run(self, costs, stream=None):
+        c = costs._c()
+        _lib.check(_lib.lib().poa_batch_run(self.handle, C.byref(c), C.c_void_p(stream or 0)))
+
+    def fetch(self, want_pairs=True):
+        n = self.n
+        score, flags = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        pair_off = np.zeros(n + 1, np.uint64)
+        pairs = np.zeros((max(self.pair_capacity, 1), 2), np.uint32) if want_pairs else None
+        st = _lib.PoaStats()
+        _lib.check(_lib.lib().poa_batch_fetch(self.handle, _p(score), _p(pairs), _p(pair_off), self.pair_capacity,
+                                              _p(flags), C.byref(st)))
+        if want_pairs:
+            pairs = pairs[:int(pair_off[n])]
+        return BatchResult(score, pairs, pair_off, flags, st.as_dict())
+
+    def device_results(self):
+        ptrs = [C.c_void_p() for _ in range(4)]
+        _lib.check(_lib.lib().poa_batch_device_results(self.handle, *[C.byref(p) for p in ptrs]))
+        return dict(zip(("score", "flags", "pair_off", "pairs"), [p.value for p in ptrs]))
+
+    def planes(self, query):
+        rows = self.dg.graph.n
+        cols = int(self.qoff[query + 1] - self.qoff[query]) + 1
+        m, i, d = (np.zeros((rows, cols), np.uint32) for _ in range(3))
+        _lib.check(_lib.lib().poa_batch_fetch_planes(self.handle, query, _p(m), _p(i), _p(d)))
+        return m, i, d
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().poa_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PoastaAligner:
+    """`PoastaAligner::new(config, aln_type)` (mod.rs:53)."""
+
+    def __init__(self, config, aln_type=AlignmentType.Global, device=0):
+        if aln_type != AlignmentType.Global:
+            raise NotImplementedError("only AlignmentType::Global runs on the GPU path (SURVEY.md §8(f) row 2)")
+        self.config, self.aln_type, self.device = config, aln_type, device
+
+    # -- the three reference entry points; all run the same dense pass ------------------------
+    def align(self, ref_graph, seq):
+        """mod.rs:114-145."""
+        return self.align_batch(ref_graph, [seq]).result(0)
+
+    def align_with_existing_bubbles(self, ref_graph, seq, existing_bubbles=None):
+        """mod.rs:69-79.  The bubble index only steers the reference's pruning; unused here."""
+        return self.align(ref_graph, seq)
+
+    def align_no_pruning(self, ref_graph, seq):
+        """mod.rs:81-90."""
+        return self.align(ref_graph, seq)
+
+    # -- batch shape (lasagna.rs:246-268) ------------------------------------------------------
+    def align_batch(self, ref_graph, seqs=None, qseq=None, qoff=None, want_pairs=True):
+        dg = _device_graph(ref_graph)
+        if seqs is not None:
+            qseq, qoff = pack_queries(seqs)
+        qseq = np.ascontiguousarray(qseq, np.uint8)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        n = len(qoff) - 1
+        score, flags = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        pair_off = np.zeros(n + 1, np.uint64)
+        cap = int(qoff[-1]) + n * dg.graph.n
+        pairs = np.zeros((max(cap, 1), 2), np.uint32) if want_pairs else None
+        st = _lib.PoaStats()
+        c = self.config.costs._c()
+        _lib.check(_lib.lib().poa_align_batch(dg.handle, C.byref(c), n, _p(qseq), _p(qoff), _p(score), _p(pairs),
+                                              _p(pair_off), cap, _p(flags), C.byref(st), self.device))
+        if want_pairs:
+            pairs = pairs[:int(pair_off[n])]
+        return BatchResult(score, pairs, pair_off, flags, st.as_dict())

@@ -1,0 +1,423 @@
+// C ABI of the gfx950 POA alignment engine (include/poasta_amd.h).  Product code.
+// Host side: graph flattening, query upload, chunked score-plane workspace, kernel launches on a
+// caller-supplied HIP stream, result compaction and download.  No CPU alignment path exists here:
+// without a HIP device every entry point that computes returns POA_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/poasta_amd.h"
+#include "poa_graph.hpp"
+#include "poa_kernels.hpp"
+
+using namespace poa_amd;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(POA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+};
+}  // namespace
+
+struct poa_graph {
+    FlatGraph g;
+};
+
+struct poa_batch {
+    const poa_graph* graph = nullptr;
+    int device = 0;
+    uint32_t n_queries = 0;
+    uint64_t total_bases = 0, total_cells = 0, plane_bytes_total = 0;
+    std::vector<uint64_t> h_qoff;
+    std::vector<uint32_t> h_pitch;
+    std::vector<uint64_t> h_plane_off, h_scratch_off;
+    struct Chunk { uint32_t first, count; };
+    std::vector<Chunk> chunks;
+    uint32_t max_chunk = 0;
+    int cols_per_lane = 16;
+
+    DevBuf<RowMeta> d_rows;
+    DevBuf<uint32_t> d_pred_rows;
+    DevBuf<uint8_t> d_qseq;
+    DevBuf<uint64_t> d_qoff, d_plane_off, d_scratch_off, d_pair_off;
+    DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
+    DevBuf<uint2> d_scratch, d_pairs;
+
+    std::vector<hipEvent_t> events;  // [begin, (fwd_end, tb_end) per chunk..., end]
+    bool ran = false;
+    hipStream_t last_stream = nullptr;
+    uint32_t n_forward_launches = 0;
+    float ms_h2d = 0.f;
+
+    ~poa_batch() {
+        for (auto e : events) (void)hipEventDestroy(e);
+    }
+};
+
+extern "C" {
+
+const char* poa_version(void) { return "poasta_amd 0.1 (gfx950)"; }
+const char* poa_last_error(void) { return g_err.c_str(); }
+
+int poa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int poa_graph_create(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
+                     const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred, poa_graph_t** out) {
+    if (!out) return fail(POA_ERR_INVALID_ARG, "poa_graph_create: out is null");
+    *out = nullptr;
+    std::unique_ptr<poa_graph> h(new (std::nothrow) poa_graph);
+    if (!h) return fail(POA_ERR_OUT_OF_MEMORY, "poa_graph_create: host allocation failed");
+    std::string err;
+    int rc;
+    try {
+        rc = build_flat_graph(n, start, end, symbol, succ_off, succ, pred_off, pred, h->g, err);
+    } catch (const std::bad_alloc&) {
+        return fail(POA_ERR_OUT_OF_MEMORY, "poa_graph_create: host allocation failed");
+    }
+    if (rc != POA_OK) return fail(rc, err);
+    *out = h.release();
+    return POA_OK;
+}
+
+void poa_graph_destroy(poa_graph_t* g) { delete g; }
+uint32_t poa_graph_rows(const poa_graph_t* g) { return g ? g->g.n : 0; }
+int poa_graph_node_rows(const poa_graph_t* g, uint32_t* rank) {
+    if (!g || !rank) return fail(POA_ERR_INVALID_ARG, "poa_graph_node_rows: null argument");
+    std::memcpy(rank, g->g.node_row.data(), g->g.n * sizeof(uint32_t));
+    return POA_OK;
+}
+
+int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const uint8_t* qseq, const uint64_t* qoff,
+                     uint64_t workspace_bytes, poa_batch_t** out) {
+    if (!out) return fail(POA_ERR_INVALID_ARG, "poa_batch_create: out is null");
+    *out = nullptr;
+    if (!g || !qoff || (n_queries && qoff[n_queries] && !qseq))
+        return fail(POA_ERR_INVALID_ARG, "poa_batch_create: null argument");
+    for (uint32_t i = 0; i < n_queries; ++i) {
+        if (qoff[i + 1] < qoff[i]) return fail(POA_ERR_INVALID_ARG, "poa_batch_create: qoff not monotone");
+        if (qoff[i + 1] - qoff[i] > 0x7FFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "query longer than 2^31");
+    }
+    int ndev = poa_device_count();
+    if (ndev <= 0) return fail(POA_ERR_NO_DEVICE, "no HIP device visible: the gfx950 path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(POA_ERR_INVALID_ARG, "poa_batch_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    std::unique_ptr<poa_batch> b(new (std::nothrow) poa_batch);
+    if (!b) return fail(POA_ERR_OUT_OF_MEMORY, "host allocation failed");
+    const FlatGraph& fg = g->g;
+    b->graph = g; b->device = device; b->n_queries = n_queries;
+    const uint32_t rows = fg.n;
+    try {
+        b->h_qoff.assign(qoff, qoff + n_queries + 1);
+        b->h_pitch.resize(n_queries);
+        b->h_plane_off.resize(n_queries);
+        b->h_scratch_off.resize((size_t)n_queries + 1);
+    } catch (const std::bad_alloc&) { return fail(POA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
+
+    uint64_t scratch_total = 0, max_len = 0;
+    std::vector<uint64_t> q_plane_elems(n_queries);
+    for (uint32_t i = 0; i < n_queries; ++i) {
+        const uint64_t L = qoff[i + 1] - qoff[i];
+        max_len = std::max(max_len, L);
+        const uint32_t pitch = (uint32_t)(((L + 1 + 31) / 32) * 32);
+        b->h_pitch[i] = pitch;
+        q_plane_elems[i] = 3ull * rows * pitch;
+        b->h_scratch_off[i] = scratch_total;
+        scratch_total += L + rows;
+        b->total_bases += L;
+        b->total_cells += (uint64_t)rows * (L + 1);
+        b->plane_bytes_total += q_plane_elems[i] * 4;
+    }
+    b->h_scratch_off[n_queries] = scratch_total;
+
+    // workspace: as many queries' planes as fit; chunks reuse it.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t fixed = scratch_total * 16 + (uint64_t)n_queries * 64 + qoff[n_queries] + (64ull << 20);
+    uint64_t ws = workspace_bytes;
+    if (ws == 0) {
+        const uint64_t avail = free_b > fixed ? (uint64_t)((free_b - fixed) * 0.85) : 0;
+        ws = std::min<uint64_t>(b->plane_bytes_total, avail);
+    }
+    uint64_t biggest = 0;
+    for (uint32_t i = 0; i < n_queries; ++i) biggest = std::max(biggest, q_plane_elems[i] * 4);
+    if (ws < biggest) {
+        if (workspace_bytes == 0 || workspace_bytes < biggest) {
+            if (biggest + fixed > free_b)
+                return fail(POA_ERR_OUT_OF_MEMORY, "score planes of the largest query do not fit in device memory");
+            ws = biggest;
+        }
+    }
+    // greedy chunking
+    {
+        uint32_t first = 0;
+        uint64_t used = 0;
+        for (uint32_t i = 0; i < n_queries; ++i) {
+            const uint64_t need = q_plane_elems[i] * 4;
+            if (used + need > ws && i > first) {
+                b->chunks.push_back({first, i - first});
+                first = i; used = 0;
+            }
+            b->h_plane_off[i] = used / 4;
+            used += need;
+        }
+        if (n_queries > first) b->chunks.push_back({first, n_queries - first});
+        for (auto& c : b->chunks) b->max_chunk = std::max(b->max_chunk, c.count);
+    }
+    b->cols_per_lane = 16;
+
+    // device buffers
+    HIP_TRY(b->d_rows.alloc(fg.rows.size()));
+    HIP_TRY(b->d_pred_rows.alloc(std::max<size_t>(fg.pred_rows.size(), 1)));
+    HIP_TRY(b->d_qseq.alloc(std::max<uint64_t>(qoff[n_queries], 1)));
+    HIP_TRY(b->d_qoff.alloc((size_t)n_queries + 1));
+    HIP_TRY(b->d_pitch.alloc(std::max<uint32_t>(n_queries, 1)));
+    HIP_TRY(b->d_plane_off.alloc(std::max<uint32_t>(n_queries, 1)));
+    HIP_TRY(b->d_scratch_off.alloc((size_t)n_queries + 1));
+    HIP_TRY(b->d_pair_off.alloc((size_t)n_queries + 1));
+    HIP_TRY(b->d_score.alloc(std::max<uint32_t>(n_queries, 1)));
+    HIP_TRY(b->d_flags.alloc(std::max<uint32_t>(n_queries, 1)));
+    HIP_TRY(b->d_npairs.alloc(std::max<uint32_t>(n_queries, 1)));
+    HIP_TRY(b->d_scratch.alloc(std::max<uint64_t>(scratch_total, 1)));
+    HIP_TRY(b->d_pairs.alloc(std::max<uint64_t>(scratch_total, 1)));
+    HIP_TRY(b->d_carry.alloc(std::max<uint64_t>((uint64_t)b->max_chunk * rows, 1)));
+    if (n_queries) {
+        hipError_t e = b->d_planes.alloc(ws / 4 + 64);
+        if (e != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, std::string("score-plane workspace: ") + hipGetErrorString(e));
+    }
+
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    HIP_TRY(hipMemcpy(b->d_rows.p, fg.rows.data(), fg.rows.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
+    if (!fg.pred_rows.empty())
+        HIP_TRY(hipMemcpy(b->d_pred_rows.p, fg.pred_rows.data(), fg.pred_rows.size() * 4, hipMemcpyHostToDevice));
+    if (qoff[n_queries]) HIP_TRY(hipMemcpy(b->d_qseq.p, qseq, qoff[n_queries], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_qoff.p, qoff, ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_scratch_off.p, b->h_scratch_off.data(), ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
+    if (n_queries) {
+        HIP_TRY(hipMemcpy(b->d_pitch.p, b->h_pitch.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_plane_off.p, b->h_plane_off.data(), (size_t)n_queries * 8, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    (void)hipEventElapsedTime(&b->ms_h2d, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+
+    b->events.resize(2 + 2 * b->chunks.size());
+    for (auto& ev : b->events) HIP_TRY(hipEventCreate(&ev));
+    *out = b.release();
+    return POA_OK;
+}
+
+int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
+    if (!b || !costs) return fail(POA_ERR_INVALID_ARG, "poa_batch_run: null argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIP_TRY(hipSetDevice(b->device));
+    const FlatGraph& fg = b->graph->g;
+    b->last_stream = stream;
+    b->n_forward_launches = 0;
+    HIP_TRY(hipEventRecord(b->events[0], stream));
+    if (b->n_queries == 0) {
+        HIP_TRY(hipMemsetAsync(b->d_pair_off.p, 0, 8, stream));
+        HIP_TRY(hipEventRecord(b->events[1], stream));
+        b->ran = true;
+        return POA_OK;
+    }
+    size_t ev = 1;
+    for (const auto& ch : b->chunks) {
+        FwdParams fp;
+        fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
+        fp.first_query = ch.first; fp.n_queries = ch.count;
+        fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = b->d_plane_off.p;
+        fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
+        fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
+        const uint32_t blocks = (ch.count + 3) / 4;
+        hipLaunchKernelGGL(poa_forward_kernel<16>, dim3(blocks), dim3(256), 0, stream, fp);
+        HIP_TRY(hipGetLastError());
+        b->n_forward_launches++;
+        HIP_TRY(hipEventRecord(b->events[ev++], stream));
+
+        TbParams tp;
+        tp.rows = b->d_rows.p; tp.pred_rows = b->d_pred_rows.p; tp.n_rows = fg.n;
+        tp.start_row = fg.start_row; tp.end_row = fg.end_row;
+        tp.first_query = ch.first; tp.n_queries = ch.count;
+        tp.qseq = b->d_qseq.p; tp.qoff = b->d_qoff.p; tp.pitch = b->d_pitch.p; tp.plane_off = b->d_plane_off.p;
+        tp.planes = b->d_planes.p; tp.scratch_off = b->d_scratch_off.p; tp.scratch = b->d_scratch.p;
+        tp.score = b->d_score.p; tp.flags = b->d_flags.p; tp.n_pairs = b->d_npairs.p;
+        tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
+        hipLaunchKernelGGL(poa_traceback_kernel, dim3((ch.count + 63) / 64), dim3(64), 0, stream, tp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->events[ev++], stream));
+    }
+    hipLaunchKernelGGL(poa_scan_kernel, dim3(1), dim3(1024), 0, stream, b->d_npairs.p, b->d_pair_off.p, b->n_queries);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(poa_compact_kernel, dim3((b->n_queries + 3) / 4), dim3(256), 0, stream, b->d_scratch.p,
+                       b->d_scratch_off.p, b->d_npairs.p, b->d_pair_off.p, b->d_pairs.p, b->n_queries);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->events[ev], stream));
+    b->ran = true;
+    return POA_OK;
+}
+
+int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
+                    uint32_t* flags, poa_stats_t* stats) {
+    if (!b) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch: null batch");
+    if (!b->ran) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch: poa_batch_run has not been called");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    const uint32_t n = b->n_queries;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    std::vector<uint64_t> off_local;
+    uint64_t* off = pair_off;
+    if (!off) { off_local.resize((size_t)n + 1); off = off_local.data(); }
+    HIP_TRY(hipMemcpy(off, b->d_pair_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+    int rc = POA_OK;
+    if (n) {
+        if (score) HIP_TRY(hipMemcpy(score, b->d_score.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> fl_local;
+        uint32_t* fl = flags;
+        if (!fl && stats) { fl_local.resize(n); fl = fl_local.data(); }
+        if (fl) HIP_TRY(hipMemcpy(fl, b->d_flags.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (pairs) {
+            if (off[n] > pair_capacity) rc = fail(POA_ERR_CAPACITY, "pair_capacity too small; pair_off[n] holds the needed total");
+            else if (off[n]) HIP_TRY(hipMemcpy(pairs, b->d_pairs.p, off[n] * sizeof(poa_aln_pair_t), hipMemcpyDeviceToHost));
+        }
+        if (stats && fl) {
+            uint32_t nf = 0;
+            for (uint32_t i = 0; i < n; ++i) nf += fl[i] != 0;
+            stats->n_flagged = nf;
+        }
+    } else if (stats) {
+        stats->n_flagged = 0;
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms_d2h = 0.f;
+    (void)hipEventElapsedTime(&ms_d2h, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (stats) {
+        stats->cells = b->total_cells; stats->bases = b->total_bases; stats->plane_bytes = b->plane_bytes_total;
+        stats->n_queries = n; stats->n_chunks = (uint32_t)b->chunks.size();
+        stats->n_forward_launches = b->n_forward_launches;
+        stats->ms_h2d = b->ms_h2d; stats->ms_d2h = ms_d2h;
+        float fwd = 0.f, tb = 0.f, total = 0.f;
+        if (n) {
+            size_t ev = 1;
+            hipEvent_t prev = b->events[0];
+            for (size_t c = 0; c < b->chunks.size(); ++c) {
+                float a = 0.f, t2 = 0.f;
+                (void)hipEventElapsedTime(&a, prev, b->events[ev]);
+                (void)hipEventElapsedTime(&t2, b->events[ev], b->events[ev + 1]);
+                fwd += a; tb += t2;
+                prev = b->events[ev + 1];
+                ev += 2;
+            }
+            float tail = 0.f;
+            (void)hipEventElapsedTime(&tail, prev, b->events[ev]);
+            tb += tail;
+            (void)hipEventElapsedTime(&total, b->events[0], b->events[ev]);
+        }
+        stats->ms_forward = fwd; stats->ms_traceback = tb; stats->ms_total = total; stats->reserved = 0;
+    }
+    return rc;
+}
+
+int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** pair_off, void** pairs) {
+    if (!b) return fail(POA_ERR_INVALID_ARG, "poa_batch_device_results: null batch");
+    if (score) *score = b->d_score.p;
+    if (flags) *flags = b->d_flags.p;
+    if (pair_off) *pair_off = b->d_pair_off.p;
+    if (pairs) *pairs = b->d_pairs.p;
+    return POA_OK;
+}
+
+int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t* i, uint32_t* d) {
+    if (!b || !m || !i || !d) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: null argument");
+    if (!b->ran || query >= b->n_queries) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: bad query / not run");
+    const auto& last = b->chunks.back();
+    if (query < last.first || query >= last.first + last.count)
+        return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: the query's planes were overwritten by a later chunk");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    const uint32_t rows = b->graph->g.n, pitch = b->h_pitch[query];
+    const uint32_t cols = (uint32_t)(b->h_qoff[query + 1] - b->h_qoff[query]) + 1;
+    const uint64_t RP = (uint64_t)rows * pitch;
+    uint32_t* dst[3] = {m, i, d};
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t* src = b->d_planes.p + b->h_plane_off[query] + k * RP;
+        HIP_TRY(hipMemcpy2D(dst[k], (size_t)cols * 4, src, (size_t)pitch * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost));
+    }
+    return POA_OK;
+}
+
+void poa_batch_destroy(poa_batch_t* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    delete b;
+}
+
+int poa_align_batch(const poa_graph_t* g, const poa_costs_t* costs, uint32_t n_queries, const uint8_t* qseq,
+                    const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
+                    uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, int device) {
+    if (!g || !costs || !qoff) return fail(POA_ERR_INVALID_ARG, "poa_align_batch: null argument");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    // PoastaAligner::align, empty-graph shortcut (src/aligner/mod.rs:124-142): score 4*len, no pairs
+    if (g->g.n_real == 0) {
+        for (uint32_t i = 0; i < n_queries; ++i) {
+            const uint64_t L = qoff[i + 1] - qoff[i];
+            if (score) score[i] = (uint32_t)(L * 4);
+            if (flags) flags[i] = POA_FLAG_EMPTY_GRAPH;
+            if (pair_off) pair_off[i] = 0;
+        }
+        if (pair_off) pair_off[n_queries] = 0;
+        if (stats) { stats->n_queries = n_queries; stats->n_flagged = n_queries; }
+        return POA_OK;
+    }
+    poa_batch_t* b = nullptr;
+    int rc = poa_batch_create(g, device, n_queries, qseq, qoff, 0, &b);
+    if (rc != POA_OK) return rc;
+    rc = poa_batch_run(b, costs, nullptr);
+    if (rc == POA_OK) rc = poa_batch_fetch(b, score, pairs, pair_off, pair_capacity, flags, stats);
+    poa_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"

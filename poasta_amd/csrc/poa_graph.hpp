@@ -1,0 +1,49 @@
+// Host-side flattening of the reference's `AlignableRefGraph` view (src/graphs/mod.rs:23-53)
+// into the row-ordered tables the gfx950 kernels walk.  Product code (not the oracle).
+//
+// Row order: a topological order that keeps chains contiguous (ready-stack Kahn), so that for
+// most rows the only predecessor is the previous row and its M/D values are still in registers.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace poa_amd {
+
+enum : uint8_t {
+    ROW_START = 1,         // the start sentinel (src/graphs/poa.rs:102)
+    ROW_END = 2,           // the end sentinel  (src/graphs/poa.rs:103)
+    ROW_OPENI_ALWAYS = 4,  // has an edge to end, or >= 2 distinct child symbols
+                           // (insertion-open rule, src/aligner/scoring/gap_affine.rs:360-366,:413-421)
+    ROW_OPENI_NEVER = 8,   // no successors at all (only the end row)
+};
+
+struct RowMeta {  // 16 bytes, one per row
+    uint32_t node;        // node index in the host graph (rpos of AlignedPair)
+    uint32_t pred_begin;  // first entry in pred_rows
+    uint32_t pred_count;
+    uint8_t sym;
+    uint8_t child_sym;    // common symbol of the non-end children (valid unless ALWAYS/NEVER)
+    uint8_t flags;
+    uint8_t pad;
+};
+static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
+
+struct FlatGraph {
+    uint32_t n = 0, start = 0, end = 0;
+    uint32_t n_real = 0;                 // nodes other than start/end
+    std::vector<uint8_t> symbol;
+    std::vector<uint32_t> succ_off, succ, pred_off, pred;  // trait iteration order (node ids)
+    std::vector<uint32_t> node_row;      // node -> row
+    std::vector<RowMeta> rows;           // row -> metadata
+    std::vector<uint32_t> pred_rows;     // predecessors as rows, trait order preserved
+    uint32_t start_row = 0, end_row = 0;
+    uint32_t max_indegree = 0;
+};
+
+// Returns POA_OK or POA_ERR_*; `err` receives a description.
+int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol,
+                     const uint32_t* succ_off, const uint32_t* succ, const uint32_t* pred_off,
+                     const uint32_t* pred, FlatGraph& out, std::string& err);
+
+}  // namespace poa_amd

@@ -1,0 +1,172 @@
+"""Parity of the HIP path (through the C ABI) against the oracle.  Bit-exact: integer scores,
+(rpos, qpos) pairs, flags and — for small cases — every cell of the M/I/D planes."""
+import numpy as np
+import pytest
+
+from poasta_amd import workloads as W
+from poasta_amd.graph import GraphBuilder, pack_queries
+
+pytestmark = pytest.mark.gpu
+
+SCORE_UNCERTAIN = 2 | 8  # POA_FLAG_START_QUIRK | POA_FLAG_SHORT_QUERY
+
+
+def _costs(engine, m=4, o=6, e=2):
+    return engine.GapAffine(m, e, o)  # reference ctor order: (mismatch, extend, open)
+
+
+def _linear_graph(seq):
+    b = GraphBuilder()
+    b.add_path(np.frombuffer(seq, np.uint8))
+    return b.finish()
+
+
+def _check_against_dense(engine, oracle, g, qs, costs=(4, 6, 2), planes=False):
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    oc = oracle.Costs(*costs)
+    qseq, qoff = pack_queries(qs)
+    al = engine.PoastaAligner(engine.AffineMinGapCost(_costs(engine, *costs)))
+    if planes:
+        rb = engine.ResidentBatch(g, qseq, qoff)
+        rb.run(_costs(engine, *costs))
+        res = rb.fetch()
+        node_rows = rb.dg.node_rows()
+        orank = og.export_csr()["rank"]
+    else:
+        res = al.align_batch(g, qseq=qseq, qoff=qoff)
+    D = og.dense_batch(qseq, qoff, oc, threads=4)
+    for i in range(len(qs)):
+        assert int(res.score[i]) == int(D["score"][i]), "score of query %d" % i
+        assert res.raw_alignment(i) == oracle.batch_alignment(D, i), "alignment of query %d" % i
+        assert int(res.flags[i]) == int(D["flags"][i]), "flags of query %d" % i
+    if planes:
+        for i in range(len(qs)):
+            m, ii, d = rb.planes(i)
+            od = og.dense_align(qs[i], oc, planes=True)
+            for name, gp, op in (("M", m, od["M"]), ("I", ii, od["I"]), ("D", d, od["D"])):
+                # rows are ranks; map node -> row on both sides
+                assert np.array_equal(gp[node_rows], op[orank]), "plane %s of query %d" % (name, i)
+        rb.close()
+    return res, D
+
+
+def _check_against_astar(oracle, g, qs, res, costs=(4, 6, 2)):
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    qseq, qoff = pack_queries(qs)
+    A = og.astar_batch(qseq, qoff, oracle.Costs(*costs), oracle.H_MINGAP, True, threads=4)
+    n_certified = 0
+    for i in range(len(qs)):
+        if A["status"][i] != 0:
+            continue
+        f = int(res.flags[i])
+        if not f & SCORE_UNCERTAIN:
+            assert int(res.score[i]) == int(A["score"][i]), "score vs A* of query %d" % i
+        if f == 0:
+            n_certified += 1
+            assert res.raw_alignment(i) == oracle.batch_alignment(A, i), "certified alignment vs A* of query %d" % i
+    return n_certified
+
+
+def test_hand_traced_known_answers(engine, oracle):
+    """SURVEY.md appendix C (hand-traced from the reference source)."""
+    cases = [(b"ACGT", b"ACGT", (4, 6, 2), 0), (b"ACGT", b"AC", (1, 10, 2), 14), (b"AAAC", b"AAC", (4, 6, 2), 8),
+             (b"AC", b"AAC", (4, 6, 2), 8), (b"AAAA", b"TTTT", (2, 8, 1), 8)]
+    for gs, q, c, score in cases:
+        g = _linear_graph(gs)
+        res, _ = _check_against_dense(engine, oracle, g, [np.frombuffer(q, np.uint8)], c, planes=True)
+        assert int(res.score[0]) == score
+        _check_against_astar(oracle, g, [np.frombuffer(q, np.uint8)], res, c)
+    # AAAC x AAC: the deletion is right-aligned (3rd A): nodes 2,3,4,5 = A,A,A,C
+    g = _linear_graph(b"AAAC")
+    al = engine.PoastaAligner(engine.AffineMinGapCost(_costs(engine)))
+    r = al.align(g, b"AAC")
+    assert r.pairs() == [(2, 0), (3, 1), (4, None), (5, 2)] and r.flags == 0
+
+
+def test_planes_small_linearish(engine, oracle):
+    g, (qseq, qoff) = W.scaled_linearish(60, 5, 3, 12, 70)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(12)]
+    res, _ = _check_against_dense(engine, oracle, g, qs, planes=True)
+    _check_against_astar(oracle, g, qs, res)
+
+
+def test_random_dags(engine, oracle):
+    total_cert = 0
+    for seed in range(40):
+        rng = np.random.Generator(np.random.PCG64(1000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, 0.3, alpha) for _ in range(16)]
+        costs = [(4, 6, 2), (2, 8, 1), (1, 10, 2), (3, 1, 1), (4, 4, 2)][seed % 5]
+        res, _ = _check_against_dense(engine, oracle, g, qs, costs, planes=(seed < 8))
+        total_cert += _check_against_astar(oracle, g, qs, res, costs)
+    assert total_cert > 100
+
+
+def test_edge_cases(engine, oracle):
+    g = _linear_graph(b"ACGTACGTAC")
+    qs = [np.zeros(0, np.uint8), np.frombuffer(b"A", np.uint8), np.frombuffer(b"T", np.uint8),
+          np.frombuffer(b"ACGTACGTAC" * 4, np.uint8), np.frombuffer(b"AC", np.uint8),
+          np.frombuffer(b"GGGGGGGGGGGGGGGG", np.uint8), np.frombuffer(b"ACGTACGTAC", np.uint8)]
+    res, _ = _check_against_dense(engine, oracle, g, qs, planes=True)
+    _check_against_astar(oracle, g, qs, res)
+    assert int(res.score[6]) == 0 and int(res.flags[6]) == 0
+    # empty batch
+    al = engine.PoastaAligner(engine.AffineMinGapCost(_costs(engine)))
+    r = al.align_batch(g, [])
+    assert len(r) == 0
+    # empty graph: PoastaAligner::align shortcut (mod.rs:124-142): score 4 * len, no pairs
+    r = al.align_batch(GraphBuilder().finish(), [b"ACGT", b""])
+    assert r.score.tolist() == [16, 0] and r.alignment(0) == []
+
+
+def test_multi_strip_long_queries(engine, oracle):
+    """Queries longer than one 1024-column strip exercise the strip carry."""
+    g, (qseq, qoff) = W.scaled_linearish(1500, 40, 20, 4, 0)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(4)]
+    qs.append(qs[0][:1023])   # pitch exactly 1024
+    qs.append(qs[1][:1024])   # pitch 1056: second strip with a single active lane group
+    qs.append(np.concatenate([qs[2], qs[2][:700]]))  # 3 strips
+    res, _ = _check_against_dense(engine, oracle, g, qs, planes=False)
+    _check_against_astar(oracle, g, qs, res)
+    rb_res, _ = _check_against_dense(engine, oracle, g, qs[4:6], planes=True)
+
+
+def test_deep_bubbles(engine, oracle):
+    poa = W.LayeredPOA(n_layers=60, width=4, indeg=4, seed=5)
+    qs = poa.queries(10, length=0)
+    res, _ = _check_against_dense(engine, oracle, poa.graph, qs, planes=True)
+    _check_against_astar(oracle, poa.graph, qs, res)
+
+
+def test_msa_graph(engine, oracle):
+    poa = W.PangenomePOA(ref_len=400, n_hap=6, p_snp=0.02, p_indel=0.01, max_indel=6, seed=4)
+    qs = poa.queries(8, length=150)
+    res, _ = _check_against_dense(engine, oracle, poa.graph, qs, planes=True)
+    _check_against_astar(oracle, poa.graph, qs, res)
+
+
+def test_config2_sample_vs_astar(engine, oracle):
+    """BASELINE.json configs[1] shape, a 64-query sample: every score equals the A* restatement's."""
+    g, (qseq, qoff) = W.config2(n_queries=64)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(64)]
+    res, _ = _check_against_dense(engine, oracle, g, qs)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=8)
+    assert np.array_equal(res.score, A["score"])
+    _check_against_astar(oracle, g, qs, res)
+    assert res.stats["cells"] == 64 * 1002 * 1001
+
+
+def test_error_codes(engine):
+    from poasta_amd import _lib
+    # cycle
+    sym = np.array([35, 36, 65, 67], np.uint8)
+    succ_off = np.array([0, 1, 1, 2, 4], np.uint32)
+    succ = np.array([2, 3, 1, 2], np.uint32)
+    pred_off = np.array([0, 0, 1, 3, 4], np.uint32)
+    pred = np.array([3, 0, 3, 2], np.uint32)
+    from poasta_amd.graph import FlatGraph
+    with pytest.raises(_lib.PoaError) as ei:
+        engine.DeviceGraph(FlatGraph(4, 0, 1, sym, succ_off, succ, pred_off, pred))
+    assert ei.value.code == -2
