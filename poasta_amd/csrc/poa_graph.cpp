@@ -46,6 +46,18 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
             }
         }
     }
+    if (n == 2) {
+        // empty POA graph (only the sentinels; src/graphs/poa.rs:100-112): the aligner never runs on it
+        // (PoastaAligner::align shortcut, src/aligner/mod.rs:124-142) — keep a trivial row table.
+        g.node_row.assign(2, 0);
+        g.node_row[end] = 1;
+        g.rows.assign(2, RowMeta{});
+        g.rows[0].node = start; g.rows[0].sym = g.symbol[start]; g.rows[0].flags = ROW_START | ROW_OPENI_ALWAYS;
+        g.rows[1].node = end; g.rows[1].sym = g.symbol[end]; g.rows[1].flags = ROW_END | ROW_OPENI_NEVER;
+        g.start_row = 0; g.end_row = 1;
+        g.pred_rows.clear();
+        return POA_OK;
+    }
     if (g.pred_off[start + 1] != g.pred_off[start]) { err = "start node has predecessors"; return POA_ERR_NOT_A_DAG; }
     if (g.succ_off[end + 1] != g.succ_off[end]) { err = "end node has successors"; return POA_ERR_NOT_A_DAG; }
 
