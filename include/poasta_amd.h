@@ -76,8 +76,8 @@ typedef struct poa_stats {
     float ms_traceback;        /* sum of traceback + compaction kernel durations */
     float ms_h2d;              /* query upload (poa_align_batch only) */
     float ms_d2h;              /* result download (poa_align_batch / poa_batch_fetch) */
-    float ms_total;            /* first launch -> last kernel end */
-    uint32_t reserved;
+    float ms_total;            /* first launch -> last kernel end, summed over runs */
+    uint32_t n_runs;           /* poa_batch_run calls covered by the ms_* sums */
 } poa_stats_t;
 
 typedef struct poa_graph poa_graph_t;
@@ -131,6 +131,9 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
 int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream);
 int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
                     uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats);
+/* synchronise the stream and return the HIP-event timings accumulated over every poa_batch_run
+ * since the last poa_batch_stats / poa_batch_fetch call (no device->host result copy) */
+int poa_batch_stats(poa_batch_t* b, poa_stats_t* stats);
 /* device pointers of the results of the last run (valid until the next run / destroy):
  * score u32[n], flags u32[n], pair_off u64[n+1], pairs poa_aln_pair_t[pair_off[n]] */
 int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** pair_off, void** pairs);

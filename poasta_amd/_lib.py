@@ -20,7 +20,7 @@ FLAG_AMBIGUOUS, FLAG_START_QUIRK, FLAG_REF_PANIC, FLAG_SHORT_QUERY, FLAG_TRUNCAT
 # every symbol include/poasta_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = ["poa_version", "poa_last_error", "poa_device_count", "poa_graph_create", "poa_graph_destroy",
            "poa_graph_rows", "poa_graph_node_rows", "poa_align_batch", "poa_batch_create", "poa_batch_run",
-           "poa_batch_fetch", "poa_batch_device_results", "poa_batch_fetch_planes", "poa_batch_destroy"]
+           "poa_batch_fetch", "poa_batch_stats", "poa_batch_device_results", "poa_batch_fetch_planes", "poa_batch_destroy"]
 
 
 class PoaCosts(C.Structure):
@@ -31,10 +31,10 @@ class PoaStats(C.Structure):
     _fields_ = [("cells", C.c_uint64), ("bases", C.c_uint64), ("plane_bytes", C.c_uint64), ("n_queries", C.c_uint32),
                 ("n_chunks", C.c_uint32), ("n_forward_launches", C.c_uint32), ("n_flagged", C.c_uint32),
                 ("ms_forward", C.c_float), ("ms_traceback", C.c_float), ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),
-                ("ms_total", C.c_float), ("reserved", C.c_uint32)]
+                ("ms_total", C.c_float), ("n_runs", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ }
 
 
 class PoaError(RuntimeError):
@@ -84,6 +84,8 @@ def lib():
     L.poa_batch_run.argtypes = [vp, C.POINTER(PoaCosts), vp]
     L.poa_batch_fetch.restype = C.c_int
     L.poa_batch_fetch.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.POINTER(PoaStats)]
+    L.poa_batch_stats.restype = C.c_int
+    L.poa_batch_stats.argtypes = [vp, C.POINTER(PoaStats)]
     L.poa_batch_device_results.restype = C.c_int
     L.poa_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.poa_batch_fetch_planes.restype = C.c_int

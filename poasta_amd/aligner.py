@@ -191,6 +191,12 @@ class ResidentBatch:
             pairs = pairs[:int(pair_off[n])]
         return BatchResult(score, pairs, pair_off, flags, st.as_dict())
 
+    def stats(self):
+        """Synchronise and return HIP-event timings summed over the runs since the last call."""
+        st = _lib.PoaStats()
+        _lib.check(_lib.lib().poa_batch_stats(self.handle, C.byref(st)))
+        return st.as_dict()
+
     def device_results(self):
         ptrs = [C.c_void_p() for _ in range(4)]
         _lib.check(_lib.lib().poa_batch_device_results(self.handle, *[C.byref(p) for p in ptrs]))

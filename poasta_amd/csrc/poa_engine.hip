@@ -70,16 +70,55 @@ struct poa_batch {
     DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
     DevBuf<uint2> d_scratch, d_pairs;
 
-    std::vector<hipEvent_t> events;  // [begin, (fwd_end, tb_end) per chunk..., end]
+    // one event set per run since the last stats call: [begin, (fwd_end, tb_end) per chunk..., end]
+    std::vector<std::vector<hipEvent_t>> runs;
+    std::vector<std::vector<hipEvent_t>> free_sets;
     bool ran = false;
     hipStream_t last_stream = nullptr;
-    uint32_t n_forward_launches = 0;
     float ms_h2d = 0.f;
 
     ~poa_batch() {
-        for (auto e : events) (void)hipEventDestroy(e);
+        for (auto& r : runs) for (auto e : r) (void)hipEventDestroy(e);
+        for (auto& r : free_sets) for (auto e : r) (void)hipEventDestroy(e);
     }
 };
+
+// sums the HIP-event timings of every run recorded since the last call; the stream must be idle.
+static void collect_stats(poa_batch* b, poa_stats_t* stats) {
+    const uint32_t n = b->n_queries;
+    const uint32_t keep_flagged = stats->n_flagged;
+    stats->cells = b->total_cells; stats->bases = b->total_bases; stats->plane_bytes = b->plane_bytes_total;
+    stats->n_queries = n; stats->n_chunks = (uint32_t)b->chunks.size();
+    stats->n_flagged = keep_flagged;
+    stats->ms_h2d = b->ms_h2d; stats->ms_d2h = 0.f;
+    float fwd = 0.f, tb = 0.f, total = 0.f;
+    uint32_t launches = 0;
+    for (auto& events : b->runs) {
+        if (n) {
+            size_t ev = 1;
+            hipEvent_t prev = events[0];
+            for (size_t c = 0; c < b->chunks.size(); ++c) {
+                float a = 0.f, t2 = 0.f;
+                (void)hipEventElapsedTime(&a, prev, events[ev]);
+                (void)hipEventElapsedTime(&t2, events[ev], events[ev + 1]);
+                fwd += a; tb += t2;
+                prev = events[ev + 1];
+                ev += 2;
+                launches++;
+            }
+            float tail = 0.f, tot = 0.f;
+            (void)hipEventElapsedTime(&tail, prev, events[ev]);
+            tb += tail;
+            (void)hipEventElapsedTime(&tot, events[0], events[ev]);
+            total += tot;
+        }
+    }
+    stats->n_runs = (uint32_t)b->runs.size();
+    stats->n_forward_launches = launches;
+    stats->ms_forward = fwd; stats->ms_traceback = tb; stats->ms_total = total;
+    for (auto& r : b->runs) b->free_sets.push_back(std::move(r));
+    b->runs.clear();
+}
 
 extern "C" {
 
@@ -237,8 +276,6 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 
-    b->events.resize(2 + 2 * b->chunks.size());
-    for (auto& ev : b->events) HIP_TRY(hipEventCreate(&ev));
     *out = b.release();
     return POA_OK;
 }
@@ -249,11 +286,18 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
     HIP_TRY(hipSetDevice(b->device));
     const FlatGraph& fg = b->graph->g;
     b->last_stream = stream;
-    b->n_forward_launches = 0;
-    HIP_TRY(hipEventRecord(b->events[0], stream));
+    if (b->runs.size() >= 256) return fail(POA_ERR_UNSUPPORTED, "poa_batch_run: call poa_batch_stats/fetch at least every 256 runs");
+    std::vector<hipEvent_t> events;
+    if (!b->free_sets.empty()) { events = std::move(b->free_sets.back()); b->free_sets.pop_back(); }
+    else {
+        events.resize(2 + 2 * b->chunks.size());
+        for (auto& e : events) HIP_TRY(hipEventCreate(&e));
+    }
+    b->runs.push_back(events);
+    HIP_TRY(hipEventRecord(events[0], stream));
     if (b->n_queries == 0) {
         HIP_TRY(hipMemsetAsync(b->d_pair_off.p, 0, 8, stream));
-        HIP_TRY(hipEventRecord(b->events[1], stream));
+        HIP_TRY(hipEventRecord(events[1], stream));
         b->ran = true;
         return POA_OK;
     }
@@ -268,8 +312,7 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         const uint32_t blocks = (ch.count + 3) / 4;
         hipLaunchKernelGGL(poa_forward_kernel<16>, dim3(blocks), dim3(256), 0, stream, fp);
         HIP_TRY(hipGetLastError());
-        b->n_forward_launches++;
-        HIP_TRY(hipEventRecord(b->events[ev++], stream));
+        HIP_TRY(hipEventRecord(events[ev++], stream));
 
         TbParams tp;
         tp.rows = b->d_rows.p; tp.pred_rows = b->d_pred_rows.p; tp.n_rows = fg.n;
@@ -281,14 +324,14 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
         hipLaunchKernelGGL(poa_traceback_kernel, dim3((ch.count + 63) / 64), dim3(64), 0, stream, tp);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(b->events[ev++], stream));
+        HIP_TRY(hipEventRecord(events[ev++], stream));
     }
     hipLaunchKernelGGL(poa_scan_kernel, dim3(1), dim3(1024), 0, stream, b->d_npairs.p, b->d_pair_off.p, b->n_queries);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(poa_compact_kernel, dim3((b->n_queries + 3) / 4), dim3(256), 0, stream, b->d_scratch.p,
                        b->d_scratch_off.p, b->d_npairs.p, b->d_pair_off.p, b->d_pairs.p, b->n_queries);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->events[ev], stream));
+    HIP_TRY(hipEventRecord(events[ev], stream));
     b->ran = true;
     return POA_OK;
 }
@@ -334,30 +377,19 @@ int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (stats) {
-        stats->cells = b->total_cells; stats->bases = b->total_bases; stats->plane_bytes = b->plane_bytes_total;
-        stats->n_queries = n; stats->n_chunks = (uint32_t)b->chunks.size();
-        stats->n_forward_launches = b->n_forward_launches;
-        stats->ms_h2d = b->ms_h2d; stats->ms_d2h = ms_d2h;
-        float fwd = 0.f, tb = 0.f, total = 0.f;
-        if (n) {
-            size_t ev = 1;
-            hipEvent_t prev = b->events[0];
-            for (size_t c = 0; c < b->chunks.size(); ++c) {
-                float a = 0.f, t2 = 0.f;
-                (void)hipEventElapsedTime(&a, prev, b->events[ev]);
-                (void)hipEventElapsedTime(&t2, b->events[ev], b->events[ev + 1]);
-                fwd += a; tb += t2;
-                prev = b->events[ev + 1];
-                ev += 2;
-            }
-            float tail = 0.f;
-            (void)hipEventElapsedTime(&tail, prev, b->events[ev]);
-            tb += tail;
-            (void)hipEventElapsedTime(&total, b->events[0], b->events[ev]);
-        }
-        stats->ms_forward = fwd; stats->ms_traceback = tb; stats->ms_total = total; stats->reserved = 0;
+        collect_stats(b, stats);
+        stats->ms_d2h = ms_d2h;
     }
     return rc;
+}
+
+int poa_batch_stats(poa_batch_t* b, poa_stats_t* stats) {
+    if (!b || !stats) return fail(POA_ERR_INVALID_ARG, "poa_batch_stats: null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->ran) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    std::memset(stats, 0, sizeof(*stats));
+    collect_stats(b, stats);
+    return POA_OK;
 }
 
 int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** pair_off, void** pairs) {
