@@ -156,7 +156,7 @@ def main():
                        "workload_gen_s": round(t_gen, 2), "plane_chunks": st["n_chunks"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "poa_forward_kernel<16>", "avg_launch_ms": round(avg_launch_ms, 3),
+                         "kernel": "poa_forward_kernel<Q>", "avg_launch_ms": round(avg_launch_ms, 3),
                          "launches_timed": launches, "cells_per_launch": int(cells_per_launch),
                          "alg_bytes_per_cell": ALG_BYTES_PER_CELL,
                          "traceback_ms_per_step": round(st["ms_traceback"] / max(st["n_runs"], 1), 3)},

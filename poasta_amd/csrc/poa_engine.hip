@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -310,7 +311,17 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
         fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
         const uint32_t blocks = (ch.count + 3) / 4;
-        hipLaunchKernelGGL(poa_forward_kernel<16>, dim3(blocks), dim3(256), 0, stream, fp);
+        // quads per strip: as many as the widest plane row of the chunk needs, at most 4 (1024 columns)
+        uint32_t max_pitch = 0;
+        for (uint32_t i = ch.first; i < ch.first + ch.count; ++i) max_pitch = std::max(max_pitch, b->h_pitch[i]);
+        uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);
+        if (const char* ov = getenv("POA_FWD_QUADS")) {  // tuning override: 1, 2 or 4 quads (256 columns each) per strip
+            const int v = atoi(ov);
+            if (v == 1 || v == 2 || v == 4) quads = (uint32_t)v;
+        }
+        if (quads == 1) hipLaunchKernelGGL(poa_forward_kernel<1>, dim3(blocks), dim3(256), 0, stream, fp);
+        else if (quads == 2) hipLaunchKernelGGL(poa_forward_kernel<2>, dim3(blocks), dim3(256), 0, stream, fp);
+        else hipLaunchKernelGGL(poa_forward_kernel<4>, dim3(blocks), dim3(256), 0, stream, fp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 

@@ -15,12 +15,13 @@
 // INF = 0xFFFFFFFF == Score::Unvisited (scoring/mod.rs:64-70); every add saturates
 // (`v_add_u32 ... clamp`), so INF is absorbing and no overflow handling is needed.
 //
-// Mapping: ONE WAVEFRONT (64 lanes) PER QUERY.  Lane l owns C consecutive columns of a strip of
-// W = 64*C columns; the wave walks the rows in topological order.  The previous row's M and D
-// stay in registers (chains: predecessor == previous row); other predecessors are re-read from the
-// score planes (L2/MALL hits, they were just written).  The diagonal term needs one cross-lane
-// value per row (DPP wave_shr:1); the insertion row is a min-plus prefix scan: in-lane serial pass
-// + 6-step cross-lane scan + in-lane fix-up.  No MFMA: integer min/add only.
+// Mapping: ONE WAVEFRONT (64 lanes) PER QUERY, walking the rows in topological order over strips of
+// up to 1024 columns ("quad-striped": lane l owns 4 consecutive columns in each 256-column quad, so
+// every plane store is a contiguous 1 KiB per wave-instruction).  The previous row's M and D stay
+// in registers (chains: predecessor == previous row); other predecessors are re-read from the score
+// planes (L2/MALL hits, they were just written).  The diagonal term needs one cross-lane value per
+// quad and row (DPP wave_shr:1); the insertion row is a min-plus prefix scan: in-lane chain +
+// 6-step DPP scan per quad + uniform carry over the quads + in-lane fix-up.  No MFMA, no LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -74,29 +75,40 @@ __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b 
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xF, 0xF, false);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_inf(uint32_t x) {
+    // lanes without a source (or masked rows) receive INF
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)INF, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
 
-template <int C>
-__device__ __forceinline__ void load_row(const uint32_t* __restrict__ p, uint32_t (&v)[C]) {
-    static_assert(C % 4 == 0, "C must be a multiple of 4");
-#pragma unroll
-    for (int k = 0; k < C; k += 4) {
-        uint4 t = *reinterpret_cast<const uint4*>(p + k);
-        v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
-    }
+// Inclusive min-plus scan over the 64 lanes: P(l) = min_{i<=l} ( t(i) + (l-i)*step ).
+// DPP only (row_shr 1/2/4/8 inside 16-lane rows, then row_bcast:15 / row_bcast:31): no LDS pipe.
+// w15 = ((l&15)+1)*step and w31 = (l-31)*step are per-lane constants.
+__device__ __forceinline__ uint32_t wave_scan_min_plus(uint32_t t, uint32_t step, uint32_t w15, uint32_t w31) {
+    uint32_t P = t;
+    P = umin(P, sat_add(dpp_or_inf<0x111, 0xF>(P), step));
+    P = umin(P, sat_add(dpp_or_inf<0x112, 0xF>(P), 2 * step));
+    P = umin(P, sat_add(dpp_or_inf<0x114, 0xF>(P), 4 * step));
+    P = umin(P, sat_add(dpp_or_inf<0x118, 0xF>(P), 8 * step));
+    P = umin(P, sat_add(dpp_or_inf<0x142, 0xA>(P), w15));  // row_bcast:15 -> rows 1,3
+    P = umin(P, sat_add(dpp_or_inf<0x143, 0xC>(P), w31));  // row_bcast:31 -> rows 2,3
+    return P;
 }
-template <int C>
-__device__ __forceinline__ void store_row(uint32_t* __restrict__ p, const uint32_t (&v)[C]) {
-#pragma unroll
-    for (int k = 0; k < C; k += 4) {
-        *reinterpret_cast<uint4*>(p + k) = make_uint4(v[k], v[k + 1], v[k + 2], v[k + 3]);
-    }
-}
+
+__device__ __forceinline__ uint32_t qbyte(uint32_t packed, int k) { return (packed >> (8 * k)) & 0xFFu; }
 
 // ---------------------------------------------------------------------------------------------
-// Forward pass.  grid: one wave per query of the chunk, 4 waves (queries) per 256-thread block.
-template <int C>
+// Forward pass.  One wave per query; 4 waves (queries) per 256-thread block.
+//
+// Layout ("quad-striped"): a strip is W = Q*256 columns; lane l owns, in each of the Q quads,
+// the 4 consecutive columns  s*W + m*256 + 4*l + {0,1,2,3}.  Every global_load/store_dwordx4 of a
+// quad therefore covers 1 KiB contiguous bytes per wave-instruction (8 full 128-B lines), the
+// four quads' insertion scans are independent chains, and the column-(j-1) neighbour is an
+// in-register value except for k = 0 (one DPP wave_shr:1 per quad).
+template <int Q>
 __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
-    constexpr uint32_t W = 64 * C;
+    constexpr int C = 4 * Q;
+    constexpr uint32_t W = 256 * Q;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
@@ -112,16 +124,26 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
     uint32_t* __restrict__ carry = P.strip_carry + (uint64_t)wq * P.n_rows;
     const uint32_t x = P.cost_x, oe = P.cost_oe, e = P.cost_e;
     const uint32_t n_strips = (pitch + W - 1) / W;
+    const uint32_t step = 4 * e;                      // one lane == 4 columns
+    const uint32_t w15 = ((lane & 15u) + 1u) * step;
+    const uint32_t w31 = (lane - 31u) * step;         // only used by lanes >= 32
+    const uint32_t lane_off = 4 * lane * e;           // cost of extending an insertion to my first column of a quad
 
     for (uint32_t s = 0; s < n_strips; ++s) {
-        const uint32_t col0 = s * W + lane * C;
-        const bool active = col0 < pitch;  // pitch is a multiple of 32 >= C: a lane is all in or all out
-        // query symbols of my columns; 0xFFFF (never a symbol) beyond the query end, so that
-        // "mismatch" holds there: openD(v, j >= L) is true, as the recurrence wants.
-        uint32_t qc[C];
+        const uint32_t sbase = s * W;
+        bool act[Q];          // my 4 columns of quad m lie inside the plane row
+        uint32_t qcp[Q];      // my 4 query symbols of quad m, one per byte; 0 (never a symbol) past the end
+        uint32_t ql[Q];       // query symbol left of my first column of quad m
 #pragma unroll
-        for (int k = 0; k < C; ++k) qc[k] = (col0 + k < L) ? (uint32_t)q[col0 + k] : 0xFFFFu;
-        const uint32_t qleft = (col0 > 0 && col0 - 1 < L) ? (uint32_t)q[col0 - 1] : 0xFFFFu;
+        for (int m = 0; m < Q; ++m) {
+            const uint32_t c0 = sbase + m * 256 + 4 * lane;
+            act[m] = c0 < pitch;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk |= ((c0 + k < L) ? (uint32_t)q[c0 + k] : 0u) << (8 * k);
+            qcp[m] = pk;
+            ql[m] = (c0 > 0 && c0 - 1 < L) ? (uint32_t)q[c0 - 1] : 0u;
+        }
 
         uint32_t Mprev[C], Dprev[C];
 #pragma unroll
@@ -130,35 +152,55 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
         for (uint32_t r = 0; r < P.n_rows; ++r) {
             const RowMeta meta = P.rows[r];
             const uint32_t sym = meta.sym;
-            uint32_t PM[C], PD[C];
-            uint32_t PMl = INF;  // min over predecessors of M[p][col0 - 1]
-#pragma unroll
-            for (int k = 0; k < C; ++k) { PM[k] = INF; PD[k] = INF; }
+            const uint64_t rbase = (uint64_t)r * pitch + sbase + 4 * lane;
+            uint32_t PM[C], PD[C], PMl[Q];
 
-            bool need_fence = false;
-            for (uint32_t pe = 0; pe < meta.pred_count; ++pe)
-                need_fence |= (P.pred_rows[meta.pred_begin + pe] + 1 != r);
-            // rows written earlier by this wave are re-read below by OTHER lanes of the wave:
-            // drain the stores first (the L1 is write-through; lines are fetched from L2 afterwards).
-            if (need_fence || s > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-
-            for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
-                const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
-                const uint64_t ro = (uint64_t)pr * pitch;
-                if (pr + 1 == r) {
-                    // chain: predecessor is the previous row, still in registers
-                    uint32_t edge = INF;
-                    if (s > 0 && lane == 0) edge = Mp[ro + col0 - 1];
-                    const uint32_t left = wave_shr1(Mprev[C - 1], edge);
-                    PMl = umin(PMl, left);
+            const bool chain = (meta.pred_count == 1) && (P.pred_rows[meta.pred_begin] + 1 == r);
+            if (chain) {
+                // fast path: the only predecessor is the previous row, still in registers
+                uint32_t edge = INF;
+                if (s > 0) edge = Mp[(uint64_t)(r - 1) * pitch + sbase - 1];  // uniform address
 #pragma unroll
-                    for (int k = 0; k < C; ++k) { PM[k] = umin(PM[k], Mprev[k]); PD[k] = umin(PD[k], Dprev[k]); }
-                } else if (active) {
+                for (int m = 0; m < Q; ++m) {
+                    PMl[m] = wave_shr1(Mprev[4 * m + 3], edge);
+                    edge = (uint32_t)__builtin_amdgcn_readlane((int)Mprev[4 * m + 3], 63);
+                }
+#pragma unroll
+                for (int k = 0; k < C; ++k) { PM[k] = Mprev[k]; PD[k] = Dprev[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; ++k) { PM[k] = INF; PD[k] = INF; }
+#pragma unroll
+                for (int m = 0; m < Q; ++m) PMl[m] = INF;
+                // rows written earlier by this wave are re-read below by other lanes of the wave:
+                // drain the stores first (write-through L1; the lines are then fetched from L2).
+                if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
+                    const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
+                    const uint64_t pbase = (uint64_t)pr * pitch + sbase + 4 * lane;
                     uint32_t tm[C], td[C];
-                    load_row<C>(Mp + ro + col0, tm);
-                    load_row<C>(Dp + ro + col0, td);
-                    const uint32_t left = col0 > 0 ? Mp[ro + col0 - 1] : INF;
-                    PMl = umin(PMl, left);
+                    if (pr + 1 == r) {
+#pragma unroll
+                        for (int k = 0; k < C; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < Q; ++m) {
+                            uint4 a = make_uint4(INF, INF, INF, INF), b = a;
+                            if (act[m]) {
+                                a = *reinterpret_cast<const uint4*>(Mp + pbase + m * 256);
+                                b = *reinterpret_cast<const uint4*>(Dp + pbase + m * 256);
+                            }
+                            tm[4 * m] = a.x; tm[4 * m + 1] = a.y; tm[4 * m + 2] = a.z; tm[4 * m + 3] = a.w;
+                            td[4 * m] = b.x; td[4 * m + 1] = b.y; td[4 * m + 2] = b.z; td[4 * m + 3] = b.w;
+                        }
+                    }
+                    uint32_t edge = INF;
+                    if (s > 0) edge = Mp[(uint64_t)pr * pitch + sbase - 1];
+#pragma unroll
+                    for (int m = 0; m < Q; ++m) {
+                        PMl[m] = umin(PMl[m], wave_shr1(tm[4 * m + 3], edge));
+                        edge = (uint32_t)__builtin_amdgcn_readlane((int)tm[4 * m + 3], 63);
+                    }
 #pragma unroll
                     for (int k = 0; k < C; ++k) { PM[k] = umin(PM[k], tm[k]); PD[k] = umin(PD[k], td[k]); }
                 }
@@ -176,57 +218,56 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
                 const bool open_always = (meta.flags & ROW_OPENI_ALWAYS) != 0;
                 const bool open_never = (meta.flags & ROW_OPENI_NEVER) != 0;
                 const uint32_t csym = meta.child_sym;
-                uint32_t H[C];
-                // D and H
+                uint32_t H[C], T[Q];
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const uint32_t open = (qc[k] != sym) ? sat_add(PM[k], oe) : INF;
-                    Dc[k] = umin(sat_add(PD[k], e), open);
-                    const uint32_t pm_left = (k == 0) ? PMl : PM[k - 1];
-                    const uint32_t q_left = (k == 0) ? qleft : qc[k - 1];
-                    const uint32_t diag = sat_add(pm_left, (q_left != sym) ? x : 0u);
-                    H[k] = umin(diag, Dc[k]);
+                for (int m = 0; m < Q; ++m) {
+                    uint32_t t = INF;  // in-lane insertion chain, carry-in INF
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = 4 * m + k;
+                        const uint32_t qk = qbyte(qcp[m], k);
+                        const uint32_t open = (qk != sym) ? sat_add(PM[i], oe) : INF;
+                        Dc[i] = umin(sat_add(PD[i], e), open);
+                        const uint32_t pm_left = (k == 0) ? PMl[m] : PM[i - 1];
+                        const uint32_t q_left = (k == 0) ? ql[m] : qbyte(qcp[m], k - 1);
+                        H[i] = umin(sat_add(pm_left, (q_left != sym) ? x : 0u), Dc[i]);
+                        if (m == 0 && k == 0 && (meta.flags & ROW_START) && sbase == 0 && lane == 0) H[i] = 0;
+                        Ic[i] = t;  // value entering column i from my own earlier columns (INF for k == 0)
+                        const bool op = !open_never && (open_always || qk != csym);
+                        t = umin(sat_add(t, e), op ? sat_add(H[i], oe) : INF);
+                    }
+                    T[m] = t;  // leaves my last column of quad m (carry-in INF)
                 }
-                if ((meta.flags & ROW_START) && col0 == 0) H[0] = 0;
-                // insertion row: I[j+1] = min(I[j] + e, A[j]),  A[j] = openI ? H[j] + oe : INF
-                // in-lane pass with carry-in INF
-                uint32_t t = INF;
-                Ic[0] = INF;
+                // cross-lane: independent scans per quad, then a uniform carry chain over the quads
+                uint32_t cq = (s > 0) ? carry[r] : INF;  // insertion value entering column sbase
 #pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const bool op = !open_never && (open_always || qc[k] != csym);
-                    const uint32_t a = op ? sat_add(H[k], oe) : INF;
-                    t = umin(sat_add(t, e), a);
-                    if (k + 1 < C) Ic[k + 1] = t;
+                for (int m = 0; m < Q; ++m) {
+                    const uint32_t Pm = wave_scan_min_plus(T[m], step, w15, w31);
+                    const uint32_t excl = wave_shr1(Pm, INF);             // from earlier lanes of this quad
+                    const uint32_t cin = umin(excl, sat_add(cq, lane_off));  // ... or from before the quad
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
+                    cq = umin(sat_add(cq, 256 * e), total);
+                    Ic[4 * m] = cin;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) Ic[4 * m + k] = umin(Ic[4 * m + k], sat_add(cin, (uint32_t)k * e));
                 }
-                // cross-lane: carry(l+1) = min(carry(l) + C*e, t(l))
-                const uint32_t c0 = (s > 0) ? carry[r] : INF;  // I[r][s*W], uniform load
-                uint32_t Pv = t;
-                if (lane == 0) Pv = umin(Pv, sat_add(c0, C * e));
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(Pv, d);
-                    if (lane >= (uint32_t)d) Pv = umin(Pv, sat_add(up, (uint32_t)d * C * e));
-                }
-                uint32_t cin = __shfl_up(Pv, 1);
-                if (lane == 0) cin = c0;
-                if (n_strips > 1 && lane == 63) carry[r] = Pv;  // I[r][(s+1)*W] for the next strip
-                Ic[0] = cin;
-#pragma unroll
-                for (int k = 1; k < C; ++k) Ic[k] = umin(Ic[k], sat_add(cin, (uint32_t)k * e));
+                if (n_strips > 1 && lane == 0) carry[r] = cq;  // I[r][(s+1)*W]
 #pragma unroll
                 for (int k = 0; k < C; ++k) Mc[k] = umin(H[k], Ic[k]);
             }
 
-            if (active) {
-                const uint64_t ro = (uint64_t)r * pitch + col0;
-                store_row<C>(Mp + ro, Mc);
-                store_row<C>(Ip + ro, Ic);
-                store_row<C>(Dp + ro, Dc);
+#pragma unroll
+            for (int m = 0; m < Q; ++m) {
+                if (act[m]) {
+                    *reinterpret_cast<uint4*>(Mp + rbase + m * 256) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
+                    *reinterpret_cast<uint4*>(Ip + rbase + m * 256) = make_uint4(Ic[4 * m], Ic[4 * m + 1], Ic[4 * m + 2], Ic[4 * m + 3]);
+                    *reinterpret_cast<uint4*>(Dp + rbase + m * 256) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < C; ++k) { Mprev[k] = Mc[k]; Dprev[k] = Dc[k]; }
         }
+        if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // carry[] and edge columns for the next strip
     }
 }
 
