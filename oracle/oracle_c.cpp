@@ -208,6 +208,13 @@ int oracle_astar_align(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, 
                        uint64_t* counters) {
     auto* h = (GraphHandle*)p;
     try {
+        if (h->g.is_poa && h->g.node_count() == 0) {
+            // PoastaAligner::align shortcut (mod.rs:124-142) comes before any bubble index is built
+            *score = len == 0 ? 0 : (uint32_t)(len * 4);
+            *n_pairs = 0;
+            if (counters) counters[0] = counters[1] = counters[2] = 0;
+            return 0;
+        }
         Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
         return run_astar(h, a, seq, len, score, pairs, cap, n_pairs, counters);
     } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }

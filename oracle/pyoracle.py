@@ -180,6 +180,10 @@ class OracleGraph:
         if rc != 0:
             raise RuntimeError("InvalidAlignment" if rc == 1 else lib().oracle_last_error().decode())
 
+    def seq_start_nodes(self):
+        """Sequence(name, start_node) of every added sequence (poa.rs:21, :313-316)."""
+        return [lib().oracle_poa_seq_start(self.h, i) for i in range(lib().oracle_poa_n_sequences(self.h))]
+
     def rev_postorder(self):
         out = np.zeros(self.n, np.uint32)
         k = lib().oracle_rev_postorder(self.h, _p(out))
