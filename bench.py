@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=10000, help="queries per GPU")
     ap.add_argument("--length", type=int, default=1000)
-    ap.add_argument("--cpu-sample", type=int, default=768, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
