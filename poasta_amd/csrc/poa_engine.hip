@@ -62,6 +62,8 @@ struct poa_batch {
     struct Chunk { uint32_t first, count; };
     std::vector<Chunk> chunks;
     uint32_t max_chunk = 0;
+    uint64_t max_len = 0;
+    bool narrow = false;  // last run used u16 planes
     int cols_per_lane = 16;
 
     DevBuf<RowMeta> d_rows;
@@ -190,11 +192,12 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     for (uint32_t i = 0; i < n_queries; ++i) {
         const uint64_t L = qoff[i + 1] - qoff[i];
         max_len = std::max(max_len, L);
-        const uint32_t pitch = (uint32_t)(((L + 1 + 31) / 32) * 32);
+        const uint32_t pitch = (uint32_t)(((L + 1 + 63) / 64) * 64);
         b->h_pitch[i] = pitch;
         q_plane_elems[i] = 3ull * rows * pitch;
         b->h_scratch_off[i] = scratch_total;
         scratch_total += L + rows;
+        b->max_len = std::max<uint64_t>(b->max_len, L);
         b->total_bases += L;
         b->total_cells += (uint64_t)rows * (L + 1);
         b->plane_bytes_total += q_plane_elems[i] * 4;
@@ -302,6 +305,16 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         b->ran = true;
         return POA_OK;
     }
+    // u16 planes whenever every finite score provably fits: a score is the cost of a path of at most
+    // rows + L edges, each costing at most max(x, o + e).  POA_PLANES=32 forces u32 (debug / A-B).
+    const uint64_t worst = ((uint64_t)fg.n + b->max_len + 2) * std::max<uint32_t>(costs->mismatch, (uint32_t)costs->gap_open + costs->gap_extend);
+    bool narrow = worst <= 65534;
+    if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
+    b->narrow = narrow;
+    uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round)
+    if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
+    int quads_override = 0;
+    if (const char* ov = getenv("POA_FWD_QUADS")) quads_override = atoi(ov);  // tuning override
     size_t ev = 1;
     for (const auto& ch : b->chunks) {
         FwdParams fp;
@@ -311,17 +324,21 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
         fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
         const uint32_t blocks = (ch.count + 3) / 4;
-        // quads per strip: as many as the widest plane row of the chunk needs, at most 4 (1024 columns)
         uint32_t max_pitch = 0;
         for (uint32_t i = ch.first; i < ch.first + ch.count; ++i) max_pitch = std::max(max_pitch, b->h_pitch[i]);
-        uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);
-        if (const char* ov = getenv("POA_FWD_QUADS")) {  // tuning override: 1, 2 or 4 quads (256 columns each) per strip
-            const int v = atoi(ov);
-            if (v == 1 || v == 2 || v == 4) quads = (uint32_t)v;
+        // strip width: as narrow as the widest plane row of the chunk allows, at most 1024 columns
+        if (narrow) {
+            uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
+            if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
+            if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint16_t>), dim3(blocks), dim3(256), 0, stream, fp);
+            else hipLaunchKernelGGL((poa_forward_kernel<2, uint16_t>), dim3(blocks), dim3(256), 0, stream, fp);
+        } else {
+            uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);  // 256 columns per quad (4 x u32 per lane)
+            if (quads_override == 1 || quads_override == 2 || quads_override == 4) quads = (uint32_t)quads_override;
+            if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint32_t>), dim3(blocks), dim3(256), 0, stream, fp);
+            else if (quads == 2) hipLaunchKernelGGL((poa_forward_kernel<2, uint32_t>), dim3(blocks), dim3(256), 0, stream, fp);
+            else hipLaunchKernelGGL((poa_forward_kernel<4, uint32_t>), dim3(blocks), dim3(256), 0, stream, fp);
         }
-        if (quads == 1) hipLaunchKernelGGL(poa_forward_kernel<1>, dim3(blocks), dim3(256), 0, stream, fp);
-        else if (quads == 2) hipLaunchKernelGGL(poa_forward_kernel<2>, dim3(blocks), dim3(256), 0, stream, fp);
-        else hipLaunchKernelGGL(poa_forward_kernel<4>, dim3(blocks), dim3(256), 0, stream, fp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
@@ -333,7 +350,9 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         tp.planes = b->d_planes.p; tp.scratch_off = b->d_scratch_off.p; tp.scratch = b->d_scratch.p;
         tp.score = b->d_score.p; tp.flags = b->d_flags.p; tp.n_pairs = b->d_npairs.p;
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
-        hipLaunchKernelGGL(poa_traceback_kernel, dim3((ch.count + 63) / 64), dim3(64), 0, stream, tp);
+        tp.spec_depth = spec_depth;
+        if (narrow) hipLaunchKernelGGL(poa_traceback_kernel<uint16_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+        else hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
     }
@@ -424,9 +443,18 @@ int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t
     const uint32_t cols = (uint32_t)(b->h_qoff[query + 1] - b->h_qoff[query]) + 1;
     const uint64_t RP = (uint64_t)rows * pitch;
     uint32_t* dst[3] = {m, i, d};
-    for (int k = 0; k < 3; ++k) {
-        const uint32_t* src = b->d_planes.p + b->h_plane_off[query] + k * RP;
-        HIP_TRY(hipMemcpy2D(dst[k], (size_t)cols * 4, src, (size_t)pitch * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost));
+    if (!b->narrow) {
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t* src = b->d_planes.p + b->h_plane_off[query] + k * RP;
+            HIP_TRY(hipMemcpy2D(dst[k], (size_t)cols * 4, src, (size_t)pitch * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost));
+        }
+    } else {
+        std::vector<uint16_t> tmp((size_t)rows * cols);
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(b->d_planes.p) + b->h_plane_off[query];
+        for (int k = 0; k < 3; ++k) {
+            HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)cols * 2, base + k * RP, (size_t)pitch * 2, (size_t)cols * 2, rows, hipMemcpyDeviceToHost));
+            for (size_t t = 0; t < tmp.size(); ++t) dst[k][t] = tmp[t] == 0xFFFFu ? 0xFFFFFFFFu : tmp[t];
+        }
     }
     return POA_OK;
 }

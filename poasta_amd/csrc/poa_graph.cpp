@@ -114,6 +114,7 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
             g.pred_rows.push_back(pr);
         }
         m.flags = 0;
+        if (m.pred_count == 1 && g.pred_rows[m.pred_begin] + 1 == r) m.flags |= ROW_CHAIN;
         if (v == start) m.flags |= ROW_START;
         if (v == end) m.flags |= ROW_END;
         bool has_end_child = false, has_real = false, multi = false;

@@ -16,6 +16,7 @@ enum : uint8_t {
     ROW_OPENI_ALWAYS = 4,  // has an edge to end, or >= 2 distinct child symbols
                            // (insertion-open rule, src/aligner/scoring/gap_affine.rs:360-366,:413-421)
     ROW_OPENI_NEVER = 8,   // no successors at all (only the end row)
+    ROW_CHAIN = 16,        // exactly one predecessor and it is the previous row
 };
 
 struct RowMeta {  // 16 bytes, one per row

@@ -41,7 +41,7 @@ struct FwdParams {
     uint32_t n_queries;         // queries in this chunk
     const uint8_t* qseq;
     const uint64_t* qoff;       // [total+1]
-    const uint32_t* pitch;      // [total] columns per plane row (multiple of 32)
+    const uint32_t* pitch;      // [total] columns per plane row (multiple of 64)
     const uint64_t* plane_off;  // [total] element offset of the query's M plane in `planes`
     uint32_t* planes;           // workspace: per query [M | I | D], each n_rows * pitch
     uint32_t* strip_carry;      // [n_queries_in_chunk * n_rows] I carried between strips (long queries)
@@ -64,6 +64,7 @@ struct TbParams {
     uint32_t* flags;              // [total]
     uint32_t* n_pairs;            // [total]
     uint32_t cost_x, cost_o, cost_e;
+    uint32_t spec_depth;          // lanes that speculate per traceback round (1..64)
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -98,17 +99,54 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus(uint32_t t, uint32_t step
 __device__ __forceinline__ uint32_t qbyte(uint32_t packed, int k) { return (packed >> (8 * k)) & 0xFFu; }
 
 // ---------------------------------------------------------------------------------------------
+// Plane element types.  u32 planes hold Score values verbatim (INF = 0xFFFFFFFF).  u16 planes are
+// used when every finite score of the batch provably fits ( (rows + L + 2) * max(x, o+e) <= 65534 ):
+// INF is stored as 0xFFFF and restored on load; arithmetic is always done on u32 registers.
+template <typename T> struct PlaneIO;
+template <> struct PlaneIO<uint32_t> {
+    static constexpr int K = 4;  // columns per lane per quad == one 16-byte access
+    static __device__ __forceinline__ uint32_t get(const uint32_t* p) { return *p; }
+    static __device__ __forceinline__ void load(const uint32_t* p, uint32_t (&v)[4]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(uint32_t* p, const uint32_t* v) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct PlaneIO<uint16_t> {
+    static constexpr int K = 8;
+    static __device__ __forceinline__ uint32_t widen(uint32_t h) { return h == 0xFFFFu ? INF : h; }
+    static __device__ __forceinline__ uint32_t get(const uint16_t* p) { return widen(*p); }
+    static __device__ __forceinline__ void load(const uint16_t* p, uint32_t (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t d[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = widen(d[i] & 0xFFFFu); v[2 * i + 1] = widen(d[i] >> 16); }
+    }
+    static __device__ __forceinline__ void store(uint16_t* p, const uint32_t* v) {
+        uint32_t d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = umin(v[2 * i], 0xFFFFu) | (umin(v[2 * i + 1], 0xFFFFu) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Forward pass.  One wave per query; 4 waves (queries) per 256-thread block.
 //
-// Layout ("quad-striped"): a strip is W = Q*256 columns; lane l owns, in each of the Q quads,
-// the 4 consecutive columns  s*W + m*256 + 4*l + {0,1,2,3}.  Every global_load/store_dwordx4 of a
-// quad therefore covers 1 KiB contiguous bytes per wave-instruction (8 full 128-B lines), the
-// four quads' insertion scans are independent chains, and the column-(j-1) neighbour is an
-// in-register value except for k = 0 (one DPP wave_shr:1 per quad).
-template <int Q>
+// Layout ("quad-striped"): a strip is W = Q*64*K columns; lane l owns, in each of the Q quads,
+// the K consecutive columns  s*W + m*64*K + K*l + {0..K-1}  (K*sizeof(T) == 16 bytes).  Every
+// global_load/store_dwordx4 of a quad therefore covers 1 KiB contiguous bytes per wave-instruction
+// (8 full 128-B lines), the quads' insertion scans are independent chains, and the column-(j-1)
+// neighbour is an in-register value except for k = 0 (one DPP wave_shr:1 per quad).
+template <int Q, typename T>
 __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
-    constexpr int C = 4 * Q;
-    constexpr uint32_t W = 256 * Q;
+    using IO = PlaneIO<T>;
+    constexpr int K = IO::K;
+    constexpr int C = K * Q;
+    constexpr uint32_t QW = 64 * K;  // columns per quad
+    constexpr uint32_t W = QW * Q;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
@@ -118,32 +156,39 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
     const uint8_t* __restrict__ q = P.qseq + qbeg;
     const uint32_t pitch = P.pitch[qi];
     const uint64_t RP = (uint64_t)P.n_rows * pitch;
-    uint32_t* __restrict__ Mp = P.planes + P.plane_off[qi];
-    uint32_t* __restrict__ Ip = Mp + RP;
-    uint32_t* __restrict__ Dp = Ip + RP;
+    T* __restrict__ Mp = reinterpret_cast<T*>(P.planes) + P.plane_off[qi];
+    T* __restrict__ Ip = Mp + RP;
+    T* __restrict__ Dp = Ip + RP;
     uint32_t* __restrict__ carry = P.strip_carry + (uint64_t)wq * P.n_rows;
     const uint32_t x = P.cost_x, oe = P.cost_oe, e = P.cost_e;
     const uint32_t n_strips = (pitch + W - 1) / W;
-    const uint32_t step = 4 * e;                      // one lane == 4 columns
+    const uint32_t step = K * e;                      // one lane == K columns
     const uint32_t w15 = ((lane & 15u) + 1u) * step;
     const uint32_t w31 = (lane - 31u) * step;         // only used by lanes >= 32
-    const uint32_t lane_off = 4 * lane * e;           // cost of extending an insertion to my first column of a quad
+    const uint32_t lane_off = K * lane * e;           // cost of extending an insertion to my first column of a quad
 
     for (uint32_t s = 0; s < n_strips; ++s) {
         const uint32_t sbase = s * W;
-        bool act[Q];          // my 4 columns of quad m lie inside the plane row
-        uint32_t qcp[Q];      // my 4 query symbols of quad m, one per byte; 0 (never a symbol) past the end
-        uint32_t ql[Q];       // query symbol left of my first column of quad m
+        bool act[Q];            // my K columns of quad m lie inside the plane row
+        uint32_t qcp[C / 4];    // my query symbols, one per byte; 0 (never a symbol) past the end
+        uint32_t ql[Q];         // query symbol left of my first column of quad m
 #pragma unroll
         for (int m = 0; m < Q; ++m) {
-            const uint32_t c0 = sbase + m * 256 + 4 * lane;
+            const uint32_t c0 = sbase + m * QW + K * lane;
             act[m] = c0 < pitch;
-            uint32_t pk = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pk |= ((c0 + k < L) ? (uint32_t)q[c0 + k] : 0u) << (8 * k);
-            qcp[m] = pk;
+            for (int w = 0; w < K / 4; ++w) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = c0 + 4 * w + k;
+                    pk |= ((c < L) ? (uint32_t)q[c] : 0u) << (8 * k);
+                }
+                qcp[m * (K / 4) + w] = pk;
+            }
             ql[m] = (c0 > 0 && c0 - 1 < L) ? (uint32_t)q[c0 - 1] : 0u;
         }
+        auto qsym = [&](int i) -> uint32_t { return qbyte(qcp[i >> 2], i & 3); };  // i = m*K + k
 
         uint32_t Mprev[C], Dprev[C];
 #pragma unroll
@@ -152,18 +197,18 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
         for (uint32_t r = 0; r < P.n_rows; ++r) {
             const RowMeta meta = P.rows[r];
             const uint32_t sym = meta.sym;
-            const uint64_t rbase = (uint64_t)r * pitch + sbase + 4 * lane;
+            const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
             uint32_t PM[C], PD[C], PMl[Q];
 
-            const bool chain = (meta.pred_count == 1) && (P.pred_rows[meta.pred_begin] + 1 == r);
+            const bool chain = (meta.flags & ROW_CHAIN) != 0;
             if (chain) {
                 // fast path: the only predecessor is the previous row, still in registers
                 uint32_t edge = INF;
-                if (s > 0) edge = Mp[(uint64_t)(r - 1) * pitch + sbase - 1];  // uniform address
+                if (s > 0) edge = IO::get(Mp + (uint64_t)(r - 1) * pitch + sbase - 1);  // uniform address
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
-                    PMl[m] = wave_shr1(Mprev[4 * m + 3], edge);
-                    edge = (uint32_t)__builtin_amdgcn_readlane((int)Mprev[4 * m + 3], 63);
+                    PMl[m] = wave_shr1(Mprev[K * m + K - 1], edge);
+                    edge = (uint32_t)__builtin_amdgcn_readlane((int)Mprev[K * m + K - 1], 63);
                 }
 #pragma unroll
                 for (int k = 0; k < C; ++k) { PM[k] = Mprev[k]; PD[k] = Dprev[k]; }
@@ -177,7 +222,7 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
                 if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
                     const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
-                    const uint64_t pbase = (uint64_t)pr * pitch + sbase + 4 * lane;
+                    const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
                     uint32_t tm[C], td[C];
                     if (pr + 1 == r) {
 #pragma unroll
@@ -185,21 +230,23 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
                     } else {
 #pragma unroll
                         for (int m = 0; m < Q; ++m) {
-                            uint4 a = make_uint4(INF, INF, INF, INF), b = a;
+                            uint32_t a[K], b[K];
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { a[k] = INF; b[k] = INF; }
                             if (act[m]) {
-                                a = *reinterpret_cast<const uint4*>(Mp + pbase + m * 256);
-                                b = *reinterpret_cast<const uint4*>(Dp + pbase + m * 256);
+                                IO::load(Mp + pbase + m * QW, a);
+                                IO::load(Dp + pbase + m * QW, b);
                             }
-                            tm[4 * m] = a.x; tm[4 * m + 1] = a.y; tm[4 * m + 2] = a.z; tm[4 * m + 3] = a.w;
-                            td[4 * m] = b.x; td[4 * m + 1] = b.y; td[4 * m + 2] = b.z; td[4 * m + 3] = b.w;
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { tm[K * m + k] = a[k]; td[K * m + k] = b[k]; }
                         }
                     }
                     uint32_t edge = INF;
-                    if (s > 0) edge = Mp[(uint64_t)pr * pitch + sbase - 1];
+                    if (s > 0) edge = IO::get(Mp + (uint64_t)pr * pitch + sbase - 1);
 #pragma unroll
                     for (int m = 0; m < Q; ++m) {
-                        PMl[m] = umin(PMl[m], wave_shr1(tm[4 * m + 3], edge));
-                        edge = (uint32_t)__builtin_amdgcn_readlane((int)tm[4 * m + 3], 63);
+                        PMl[m] = umin(PMl[m], wave_shr1(tm[K * m + K - 1], edge));
+                        edge = (uint32_t)__builtin_amdgcn_readlane((int)tm[K * m + K - 1], 63);
                     }
 #pragma unroll
                     for (int k = 0; k < C; ++k) { PM[k] = umin(PM[k], tm[k]); PD[k] = umin(PD[k], td[k]); }
@@ -218,38 +265,38 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
                 const bool open_always = (meta.flags & ROW_OPENI_ALWAYS) != 0;
                 const bool open_never = (meta.flags & ROW_OPENI_NEVER) != 0;
                 const uint32_t csym = meta.child_sym;
-                uint32_t H[C], T[Q];
+                uint32_t H[C], Tq[Q];
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
                     uint32_t t = INF;  // in-lane insertion chain, carry-in INF
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int i = 4 * m + k;
-                        const uint32_t qk = qbyte(qcp[m], k);
+                    for (int k = 0; k < K; ++k) {
+                        const int i = K * m + k;
+                        const uint32_t qk = qsym(i);
                         const uint32_t open = (qk != sym) ? sat_add(PM[i], oe) : INF;
                         Dc[i] = umin(sat_add(PD[i], e), open);
                         const uint32_t pm_left = (k == 0) ? PMl[m] : PM[i - 1];
-                        const uint32_t q_left = (k == 0) ? ql[m] : qbyte(qcp[m], k - 1);
+                        const uint32_t q_left = (k == 0) ? ql[m] : qsym(i - 1);
                         H[i] = umin(sat_add(pm_left, (q_left != sym) ? x : 0u), Dc[i]);
                         if (m == 0 && k == 0 && (meta.flags & ROW_START) && sbase == 0 && lane == 0) H[i] = 0;
                         Ic[i] = t;  // value entering column i from my own earlier columns (INF for k == 0)
                         const bool op = !open_never && (open_always || qk != csym);
                         t = umin(sat_add(t, e), op ? sat_add(H[i], oe) : INF);
                     }
-                    T[m] = t;  // leaves my last column of quad m (carry-in INF)
+                    Tq[m] = t;  // leaves my last column of quad m (carry-in INF)
                 }
                 // cross-lane: independent scans per quad, then a uniform carry chain over the quads
                 uint32_t cq = (s > 0) ? carry[r] : INF;  // insertion value entering column sbase
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
-                    const uint32_t Pm = wave_scan_min_plus(T[m], step, w15, w31);
-                    const uint32_t excl = wave_shr1(Pm, INF);             // from earlier lanes of this quad
+                    const uint32_t Pm = wave_scan_min_plus(Tq[m], step, w15, w31);
+                    const uint32_t excl = wave_shr1(Pm, INF);                // from earlier lanes of this quad
                     const uint32_t cin = umin(excl, sat_add(cq, lane_off));  // ... or from before the quad
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
-                    cq = umin(sat_add(cq, 256 * e), total);
-                    Ic[4 * m] = cin;
+                    cq = umin(sat_add(cq, QW * e), total);
+                    Ic[K * m] = cin;
 #pragma unroll
-                    for (int k = 1; k < 4; ++k) Ic[4 * m + k] = umin(Ic[4 * m + k], sat_add(cin, (uint32_t)k * e));
+                    for (int k = 1; k < K; ++k) Ic[K * m + k] = umin(Ic[K * m + k], sat_add(cin, (uint32_t)k * e));
                 }
                 if (n_strips > 1 && lane == 0) carry[r] = cq;  // I[r][(s+1)*W]
 #pragma unroll
@@ -259,9 +306,9 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
 #pragma unroll
             for (int m = 0; m < Q; ++m) {
                 if (act[m]) {
-                    *reinterpret_cast<uint4*>(Mp + rbase + m * 256) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
-                    *reinterpret_cast<uint4*>(Ip + rbase + m * 256) = make_uint4(Ic[4 * m], Ic[4 * m + 1], Ic[4 * m + 2], Ic[4 * m + 3]);
-                    *reinterpret_cast<uint4*>(Dp + rbase + m * 256) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
+                    IO::store(Mp + rbase + m * QW, &Mc[K * m]);
+                    IO::store(Ip + rbase + m * QW, &Ic[K * m]);
+                    IO::store(Dp + rbase + m * QW, &Dc[K * m]);
                 }
             }
 #pragma unroll
@@ -275,12 +322,13 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
 // Traceback: the reference's score-based rule (scoring/gap_affine.rs:550-657, :804-915) applied to
 // the dense planes.  Every test of a step is evaluated so that the certificate "exactly one
 // candidate, no phantom below target" can be decided.  One thread per query.
+template <typename T>
 struct TbCtx {
     const RowMeta* rows;
     const uint32_t* pred_rows;
-    const uint32_t* M;
-    const uint32_t* I;
-    const uint32_t* D;
+    const T* M;
+    const T* I;
+    const T* D;
     const uint8_t* q;
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
@@ -291,18 +339,21 @@ struct TbStep {
     bool found;
 };
 
-__device__ __forceinline__ uint32_t pl(const uint32_t* p, uint32_t pitch, uint32_t row, uint32_t j) {
-    return p[(uint64_t)row * pitch + j];
+template <typename T>
+__device__ __forceinline__ uint32_t pl(const T* p, uint32_t pitch, uint32_t row, uint32_t j) {
+    return PlaneIO<T>::get(p + (uint64_t)row * pitch + j);
 }
 
-__device__ inline bool tb_open_i(const TbCtx& c, const RowMeta& m, uint32_t j) {
+template <typename T>
+__device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j) {
     if (j >= c.L) return false;
     if (m.flags & ROW_OPENI_ALWAYS) return true;
     if (m.flags & ROW_OPENI_NEVER) return false;
     return (uint32_t)m.child_sym != (uint32_t)c.q[j];
 }
 
-__device__ inline TbStep tb_step(const TbCtx& c, uint32_t row, uint32_t j, uint32_t st, uint32_t& n_cand,
+template <typename T>
+__device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st, uint32_t& n_cand,
                                  bool& bad, bool& panic) {
     TbStep first{0, 0, 0, false};
     n_cand = 0;
@@ -314,19 +365,27 @@ __device__ inline TbStep tb_step(const TbCtx& c, uint32_t row, uint32_t j, uint3
         n_cand++;
     };
     if (st == 0) {
+        // all loads of the step are issued before the first use (one memory round-trip for chain rows)
         const uint32_t cs = pl(c.M, c.pitch, row, j);
+        const uint32_t dv = pl(c.D, c.pitch, row, j);
+        const uint32_t iv = pl(c.I, c.pitch, row, j);
+        const uint32_t up = (row > 0 && j > 0) ? pl(c.M, c.pitch, row - 1, j - 1) : INF;  // the usual diagonal predecessor
         if (cs == INF) return first;
         if (j > 0) {
             const bool moe = is_end || ((uint32_t)m.sym == (uint32_t)c.q[j - 1]);
             const uint32_t pj = is_end ? j : j - 1;
             const uint32_t target = moe ? cs : sub(cs, c.x);
-            for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-                const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-                if (pl(c.M, c.pitch, pr, pj) == target) cand(pr, pj, 0);
+            if ((m.flags & ROW_CHAIN) && !is_end) {  // the end row reads its predecessor at the SAME column
+                if (up == target) cand(row - 1, pj, 0);
+            } else {
+                for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+                    const uint32_t pr = c.pred_rows[m.pred_begin + pe];
+                    if (pl(c.M, c.pitch, pr, pj) == target) cand(pr, pj, 0);
+                }
             }
         }
-        if (pl(c.D, c.pitch, row, j) == cs) cand(row, j, 1);
-        if (pl(c.I, c.pitch, row, j) == cs) cand(row, j, 2);
+        if (dv == cs) cand(row, j, 1);
+        if (iv == cs) cand(row, j, 2);
     } else if (st == 1) {
         const uint32_t cs = pl(c.D, c.pitch, row, j);
         if (cs == INF) return first;
@@ -362,18 +421,26 @@ __device__ inline TbStep tb_step(const TbCtx& c, uint32_t row, uint32_t j, uint3
     return first;
 }
 
-__global__ __launch_bounds__(64) void poa_traceback_kernel(TbParams P) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.n_queries) return;
-    const uint32_t qi = P.first_query + t;
+// One WAVE per query.  A traceback is a chain of dependent reads (~2 us each from HBM): to cut the
+// chain, lane i speculatively evaluates the step at cell (row - i, j - i) — where the path is if
+// the previous i steps were all (mis)match steps to the previous row — and the longest prefix of
+// lanes whose step really is that diagonal move is accepted at once.  The first lane that deviates
+// (gap open/close, bubble predecessor, start reached) is then handled exactly like the sequential
+// rule, so the emitted alignment and flags are identical to a step-by-step walk.
+template <typename T>
+__global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    if (wq >= P.n_queries) return;
+    const uint32_t qi = P.first_query + wq;
     const uint64_t qbeg = P.qoff[qi];
-    TbCtx c;
+    TbCtx<T> c;
     c.rows = P.rows; c.pred_rows = P.pred_rows;
     c.L = (uint32_t)(P.qoff[qi + 1] - qbeg);
     c.q = P.qseq + qbeg;
     c.pitch = P.pitch[qi];
     const uint64_t RP = (uint64_t)P.n_rows * c.pitch;
-    c.M = P.planes + P.plane_off[qi];
+    c.M = reinterpret_cast<const T*>(P.planes) + P.plane_off[qi];
     c.I = c.M + RP;
     c.D = c.I + RP;
     c.start_row = P.start_row; c.end_row = P.end_row;
@@ -382,68 +449,113 @@ __global__ __launch_bounds__(64) void poa_traceback_kernel(TbParams P) {
 
     uint2* out = P.scratch + P.scratch_off[qi];
     const uint32_t cap = (uint32_t)(P.scratch_off[qi + 1] - P.scratch_off[qi]);
-    uint32_t cnt = 0;
-    uint32_t flags = 0;
-    auto emit = [&](uint32_t rpos, uint32_t qpos) {
-        if (cnt < cap) out[cap - 1 - cnt] = make_uint2(rpos, qpos);
-        cnt++;
+    uint32_t cnt = 0;    // wave-uniform
+    uint32_t flags = 0;  // wave-uniform
+    auto emit_at = [&](uint32_t pos, uint32_t rpos, uint32_t qpos) {
+        if (pos < cap) out[cap - 1 - pos] = make_uint2(rpos, qpos);
     };
+    auto bc = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); };
 
-    P.score[qi] = pl(c.M, c.pitch, c.end_row, L);
+    if (lane == 0) P.score[qi] = pl(c.M, c.pitch, c.end_row, L);
     const uint32_t end_node = c.rows[c.end_row].node;
 
     bool done = false;
+    uint32_t crow = 0, cj = 0, cst = 0;
     if (L == 0) done = true;
     if (!done && L == 1) {
         // gap_affine.rs:812-824: the end node equals every symbol -> always [(end, 0)]
         flags |= POA_FLAG_SHORT_QUERY;
-        emit(end_node, 0);
+        if (lane == 0) emit_at(0, end_node, 0);
+        cnt = 1;
         done = true;
     }
     if (!done) {
-        uint32_t nc; bool bad = false, pn = false;
-        TbStep cur = tb_step(c, c.end_row, L, 0, nc, bad, pn);
-        if (pn) flags |= POA_FLAG_REF_PANIC;
-        if (cur.found && (nc != 1 || bad)) flags |= POA_FLAG_AMBIGUOUS;
-        if (!cur.found) {
-            // .or_else(Insertion).or_else(Deletion), gap_affine.rs:832-835
-            cur = tb_step(c, c.end_row, L, 2, nc, bad, pn);
-            if (!cur.found) cur = tb_step(c, c.end_row, L, 1, nc, bad, pn);
+        // first hop from the end cell: Match, .or_else(Insertion), .or_else(Deletion) (gap_affine.rs:832-835)
+        uint32_t f0 = 0, fr = 0, fj = 0, fs = 0, fallback = 0;
+        if (lane == 0) {
+            uint32_t nc; bool bad = false, pn = false;
+            TbStep cur = tb_step(c, c.end_row, L, 0, nc, bad, pn);
+            if (pn) f0 |= POA_FLAG_REF_PANIC;
+            if (cur.found && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
             if (!cur.found) {
-                flags |= POA_FLAG_REF_PANIC;
-                if (L <= 3) for (uint32_t i = 0; i < L; ++i) emit(end_node, L - 1 - i);
-                done = true;
-            } else {
-                flags |= POA_FLAG_AMBIGUOUS;
+                cur = tb_step(c, c.end_row, L, 2, nc, bad, pn);
+                if (!cur.found) cur = tb_step(c, c.end_row, L, 1, nc, bad, pn);
+                if (!cur.found) { f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
+                else f0 |= POA_FLAG_AMBIGUOUS;
             }
+            fr = cur.row; fj = cur.j; fs = cur.st;
         }
-        if (!done) {
-            uint32_t crow = cur.row, cj = cur.j, cst = cur.st;
-            bool reached_start = false;
-            for (;;) {
-                bad = false; pn = false;
-                const TbStep bt = tb_step(c, crow, cj, cst, nc, bad, pn);
-                if (pn) flags |= POA_FLAG_REF_PANIC;
-                if (!bt.found) break;
-                if (nc != 1 || bad) flags |= POA_FLAG_AMBIGUOUS;
-                if (cst == 0 && bt.st != 0) { crow = bt.row; cj = bt.j; cst = bt.st; continue; }
-                const uint32_t node = c.rows[crow].node;
-                if (cst == 0) emit(node, cj - 1);
-                else if (cst == 2) emit(POA_NONE, cj - 1);
-                else emit(node, POA_NONE);
-                // start-quirk certificate (dfa.rs:146-167): this step used an out-edge of
-                // (bt.row, 0, M) whose node symbol equals q[0]
-                if (bt.st == 0 && bt.j == 0 && bt.row != c.start_row && cst != 1 &&
-                    (uint32_t)c.rows[bt.row].sym == (uint32_t)c.q[0])
-                    flags |= POA_FLAG_START_QUIRK;
-                if (bt.row == c.start_row) { reached_start = true; break; }
-                crow = bt.row; cj = bt.j; cst = bt.st;
+        flags |= bc(f0, 0);
+        if (bc(fallback, 0)) {
+            if (L <= 3) {
+                if (lane == 0) for (uint32_t i = 0; i < L; ++i) emit_at(i, end_node, L - 1 - i);
+                cnt = L;
             }
-            if (!reached_start) flags |= POA_FLAG_TRUNCATED;
+            done = true;
+        } else {
+            crow = bc(fr, 0); cj = bc(fj, 0); cst = bc(fs, 0);
         }
     }
-    P.flags[qi] = flags;
-    P.n_pairs[qi] = cnt < cap ? cnt : cap;
+    bool reached_start = done;  // nothing to truncate in the special cases
+    while (!done) {
+        uint32_t depth = 1;
+        if (cst == 0) {
+            depth = P.spec_depth;
+            if (crow + 1 < depth) depth = crow + 1;
+            if (cj + 1 < depth) depth = cj + 1;
+        }
+        const bool active = lane < depth;
+        const uint32_t my_row = crow - lane, my_j = cj - lane;
+        TbStep bt{0, 0, 0, false};
+        uint32_t nc = 0;
+        bool bad = false, pn = false;
+        if (active) bt = tb_step(c, my_row, my_j, cst, nc, bad, pn);
+        const bool amb = active && bt.found && (nc != 1 || bad);
+        const bool quirk = active && bt.found && bt.st == 0 && bt.j == 0 && bt.row != c.start_row && cst != 1 &&
+                           (uint32_t)c.rows[bt.row].sym == (uint32_t)c.q[0];
+        // a "regular" step: (mis)match into exactly the cell the next lane speculated on, not yet at start
+        const bool regular = active && cst == 0 && bt.found && bt.st == 0 && bt.row + 1 == my_row &&
+                             bt.j + 1 == my_j && bt.row != c.start_row;
+        const uint64_t rb = __ballot(regular);
+        const uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
+        const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
+        if (__ballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
+        if (__ballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
+        if (__ballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
+        if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, my_j - 1);
+        cnt += p;
+        if (p == depth) {
+            // every speculated step was regular: continue below the last one
+            crow -= depth; cj -= depth;  // state stays Match
+            continue;
+        }
+        // lane p deviates: replay the sequential rule with its results
+        const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
+        const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_pn = bc(pn ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
+        const uint32_t cur_row = crow - p, cur_j = cj - p, cur_st = (p == 0) ? cst : 0u;
+        if (d_pn) flags |= POA_FLAG_REF_PANIC;
+        if (!d_found) break;
+        if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
+        if (cur_st == 0 && d_st != 0) {  // zero-cost gap close: no pair (gap_affine.rs:871-875)
+            crow = d_row; cj = d_j; cst = d_st;
+            continue;
+        }
+        if (lane == 0) {
+            const uint32_t node = c.rows[cur_row].node;
+            if (cur_st == 0) emit_at(cnt, node, cur_j - 1);
+            else if (cur_st == 2) emit_at(cnt, POA_NONE, cur_j - 1);
+            else emit_at(cnt, node, POA_NONE);
+        }
+        cnt += 1;
+        if (d_quirk) flags |= POA_FLAG_START_QUIRK;
+        if (d_row == c.start_row) { reached_start = true; break; }
+        crow = d_row; cj = d_j; cst = d_st;
+    }
+    if (!reached_start) flags |= POA_FLAG_TRUNCATED;
+    if (lane == 0) {
+        P.flags[qi] = flags;
+        P.n_pairs[qi] = cnt < cap ? cnt : cap;
+    }
 }
 
 // exclusive prefix sum of n_pairs -> pair_off[n+1]; single block.
