@@ -47,6 +47,15 @@ extern "C" {
 #define POA_FLAG_SHORT_QUERY 0x08u  /* len <= 1: reference special cases (gap_affine.rs:808-824) */
 #define POA_FLAG_TRUNCATED 0x10u    /* backtrace ended before the start node (as the reference's would) */
 #define POA_FLAG_EMPTY_GRAPH 0x20u  /* no real nodes: PoastaAligner::align shortcut (mod.rs:124-142), score 4*len */
+#define POA_FLAG_EXACT_OVERFLOW 0x40u /* exact replay ran out of workspace: the dense result (and its flags) was kept */
+
+/* modes (poa_config_t.mode) */
+#define POA_MODE_DENSE 0u   /* dense planes + traceback: scores exact, alignment certified-or-flagged */
+#define POA_MODE_EXACT 1u   /* dense pass, then a replay of the reference's own A* search (same pop order, greedy
+                               extension and pruning) for EVERY query: alignments bit-identical incl. tie-breaks */
+#define POA_MODE_HYBRID 2u  /* dense pass, then the exact replay only for queries whose dense flags are non-zero */
+#define POA_HEURISTIC_DIJKSTRA 0u /* AffineDijkstra   (src/aligner/config.rs:49)  */
+#define POA_HEURISTIC_MINGAP 1u   /* AffineMinGapCost (src/aligner/config.rs:104), the default of both reference CLIs */
 
 /* GapAffine (gap_affine.rs:20-24).  NB the Rust constructor order is (mismatch, extend, open). */
 typedef struct poa_costs {
@@ -55,6 +64,15 @@ typedef struct poa_costs {
     uint8_t gap_extend;
     uint8_t reserved;
 } poa_costs_t;
+
+/* Which reference configuration the exact replay emulates (only the replay depends on it: heuristic and pruning
+ * fix the reference's search order, not its optimum).  Zero-initialised == dense mode. */
+typedef struct poa_config {
+    uint32_t mode;            /* POA_MODE_* */
+    uint32_t heuristic;       /* POA_HEURISTIC_* (replay only) */
+    uint32_t pruning;         /* 1: align / align_with_existing_bubbles; 0: align_no_pruning (mod.rs:81-90) */
+    float queue_entries_per_cell; /* replay queue pool, entries per (row x column) cell; 0 = default 0.25 */
+} poa_config_t;
 
 /* AlignedPair (alignment.rs:4-13): rpos = node index of the host graph, qpos = 0-based query position */
 typedef struct poa_aln_pair {
@@ -76,6 +94,8 @@ typedef struct poa_stats {
     float ms_traceback;        /* sum of traceback + compaction kernel durations */
     float ms_h2d;              /* query upload (poa_align_batch only) */
     float ms_d2h;              /* result download (poa_align_batch / poa_batch_fetch) */
+    float ms_exact;            /* exact-replay search kernels (+ their traceback), 0 in dense mode */
+    uint32_t n_exact;          /* queries whose result came from the exact replay (last run) */
     float ms_total;            /* first launch -> last kernel end, summed over runs */
     uint32_t n_runs;           /* poa_batch_run calls covered by the ms_* sums */
 } poa_stats_t;
@@ -120,6 +140,11 @@ int poa_align_batch(const poa_graph_t* g, const poa_costs_t* costs, uint32_t n_q
                     const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
                     poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
                     uint32_t* flags, poa_stats_t* stats, int device);
+/* same with a mode (cfg NULL == dense) */
+int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa_config_t* cfg, uint32_t n_queries,
+                       const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
+                       poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
+                       uint32_t* flags, poa_stats_t* stats, int device);
 
 /* ---- resident batch (queries and results stay in HBM; used by the multi-GPU driver) ------ */
 /* poa_batch_create uploads graph + queries to `device` and sizes the score-plane workspace
@@ -129,6 +154,8 @@ int poa_align_batch(const poa_graph_t* g, const poa_costs_t* costs, uint32_t n_q
 int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const uint8_t* qseq,
                      const uint64_t* qoff, uint64_t workspace_bytes, poa_batch_t** out);
 int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream);
+/* same with a mode: cfg NULL == dense */
+int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_t* cfg, void* stream);
 int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
                     uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats);
 /* synchronise the stream and return the HIP-event timings accumulated over every poa_batch_run

@@ -305,3 +305,164 @@ int oracle_dense_batch(void* p, uint8_t m, uint8_t o, uint8_t e, uint32_t n_quer
 }
 
 }  // extern "C"
+
+// ---- diagnostics: where does the reference's traceback leave the dense rule? ----------------
+// For one query: run A* (table T_A) and the dense pass (T_R), walk the REFERENCE's backtrace and at
+// each step list the dense candidates; report the first step where the reference's pick is not the
+// first dense candidate.  out[0]=diverged(0/1), out[1]=state, out[2]=n_dense_candidates,
+// out[3]=index of the reference's pick among dense candidates (or 99), out[4]=first dense candidate
+// visited-at-optimal in T_A (0/1), out[5]=T_A value of first dense candidate (or UNVISITED),
+// out[6]=T_R value, out[7]=step index, out[8..10] = kind of first dense cand (state), kind of ref pick (state), cur offset
+extern "C" int oracle_tie_report(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, const uint8_t* seq,
+                                 uint64_t len, uint64_t* out) {
+    auto* h = (GraphHandle*)p;
+    try {
+        Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        AstarResult ar = A.astar_alignment(seq, len);
+        DenseAligner D(h->g, Costs{m, o, e});
+        DenseResult R;
+        D.forward(seq, len, R);
+        const size_t P = R.pitch;
+        auto rank = D.rank;
+        auto TR = [&](uint32_t node, size_t j, AlignState st) -> Score {
+            const auto& pl = st == ST_M ? R.M : (st == ST_I ? R.I : R.D);
+            return pl[rank[node] * P + j];
+        };
+        // enumerate dense candidates of one step in reference test order
+        struct Cand { uint32_t node; uint32_t j; AlignState st; };
+        auto cands = [&](uint32_t v, uint32_t j, AlignState st) {
+            std::vector<Cand> c;
+            const Graph& g = h->g;
+            Score cs = TR(v, j, st);
+            if (cs == UNVISITED) return c;
+            if (st == ST_M) {
+                if (j > 0) {
+                    bool moe = g.is_symbol_equal(v, seq[j - 1]) || v == g.end;
+                    uint32_t pj = v == g.end ? j : j - 1;
+                    Score target = moe ? cs : cs - m;
+                    for (uint32_t pr : g.pred[v]) if (TR(pr, pj, ST_M) == target) c.push_back({pr, pj, ST_M});
+                }
+                if (TR(v, j, ST_D) == cs) c.push_back({v, j, ST_D});
+                if (TR(v, j, ST_I) == cs) c.push_back({v, j, ST_I});
+            } else if (st == ST_D) {
+                for (uint32_t pr : g.pred[v]) if (TR(pr, j, ST_M) == cs - o - e) c.push_back({pr, j, ST_M});
+                for (uint32_t pr : g.pred[v]) if (TR(pr, j, ST_D) == cs - e) c.push_back({pr, j, ST_D});
+            } else if (j > 0) {
+                if (TR(v, j - 1, ST_M) == cs - o - e) c.push_back({v, j - 1, ST_M});
+                if (TR(v, j - 1, ST_I) == cs - e) c.push_back({v, j - 1, ST_M});
+            }
+            return c;
+        };
+        for (int k = 0; k < 12; ++k) out[k] = 0;
+        // walk the reference's own backtrace
+        AlnNode cur{h->g.end, (uint32_t)len}; AlignState cst = ST_M;
+        uint64_t step = 0;
+        AlnNode bt; AlignState bst;
+        while (A.get_backtrace(cur, cst, bt, bst)) {
+            auto c = cands(cur.node, cur.offset, cst);
+            int idx = 99;
+            for (size_t i = 0; i < c.size(); ++i)
+                if (c[i].node == bt.node && c[i].j == bt.offset && c[i].st == bst) { idx = (int)i; break; }
+            if (idx != 0) {
+                out[0] = 1; out[1] = cst; out[2] = c.size(); out[3] = idx;
+                if (!c.empty()) {
+                    Score ta = A.visited.get_score({c[0].node, c[0].j}, c[0].st);
+                    Score tr = TR(c[0].node, c[0].j, c[0].st);
+                    out[4] = (ta == tr); out[5] = ta; out[6] = tr; out[8] = c[0].st;
+                }
+                out[7] = step; out[9] = bst; out[10] = cur.offset; out[11] = ar.score;
+                return 0;
+            }
+            if (bt.node == h->g.start) break;
+            cur = bt; cst = bst; step++;
+        }
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+// Tie census: for every step of the reference's backtrace with >= 2 dense candidates, record
+// (signature of candidate kinds, which one the reference took).  Signature: per candidate one char
+// m (diag pred), d (D close / D pred), i (I close) ...; written as text lines into buf.
+extern "C" int oracle_tie_census(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, const uint8_t* seq,
+                                 uint64_t len, char* buf, uint64_t cap) {
+    auto* h = (GraphHandle*)p;
+    try {
+        Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        A.astar_alignment(seq, len);
+        DenseAligner D(h->g, Costs{m, o, e});
+        DenseResult R;
+        D.forward(seq, len, R);
+        const size_t P = R.pitch;
+        auto rank = D.rank;
+        const Graph& g = h->g;
+        auto TR = [&](uint32_t node, size_t j, AlignState st) -> Score {
+            const auto& pl = st == ST_M ? R.M : (st == ST_I ? R.I : R.D);
+            return pl[rank[node] * P + j];
+        };
+        struct Cand { uint32_t node; uint32_t j; AlignState st; char kind; };
+        std::string outs;
+        AlnNode cur{g.end, (uint32_t)len}; AlignState cst = ST_M;
+        AlnNode bt; AlignState bst;
+        while (A.get_backtrace(cur, cst, bt, bst)) {
+            std::vector<Cand> c;
+            uint32_t v = cur.node, j = cur.offset;
+            Score cs = TR(v, j, cst);
+            Score csA = A.visited.get_score(cur, cst);
+            if (cs == csA) {
+                if (cst == ST_M) {
+                    if (j > 0) {
+                        bool moe = g.is_symbol_equal(v, seq[j - 1]) || v == g.end;
+                        uint32_t pj = v == g.end ? j : j - 1;
+                        Score target = moe ? cs : cs - m;
+                        for (uint32_t pr : g.pred[v]) if (TR(pr, pj, ST_M) == target) c.push_back({pr, pj, ST_M, moe ? 'm' : 'x'});
+                    }
+                    if (TR(v, j, ST_D) == cs) c.push_back({v, j, ST_D, 'd'});
+                    if (TR(v, j, ST_I) == cs) c.push_back({v, j, ST_I, 'i'});
+                } else if (cst == ST_D) {
+                    for (uint32_t pr : g.pred[v]) if (TR(pr, j, ST_M) == cs - o - e) c.push_back({pr, j, ST_M, 'O'});
+                    for (uint32_t pr : g.pred[v]) if (TR(pr, j, ST_D) == cs - e) c.push_back({pr, j, ST_D, 'E'});
+                } else if (j > 0) {
+                    if (TR(v, j - 1, ST_M) == cs - o - e) c.push_back({v, j - 1, ST_M, 'O'});
+                    if (TR(v, j - 1, ST_I) == cs - e) c.push_back({v, j - 1, ST_M, 'E'});
+                }
+                if (c.size() >= 2) {
+                    int idx = -1;
+                    for (size_t i = 0; i < c.size(); ++i)
+                        if (c[i].node == bt.node && c[i].j == bt.offset && c[i].st == bst) { idx = (int)i; break; }
+                    std::string sig = cst == ST_M ? "M:" : (cst == ST_D ? "D:" : "I:");
+                    for (auto& k : c) sig.push_back(k.kind);
+                    sig += " ref=" + std::to_string(idx);
+                    // which candidates are visited-at-optimal in the reference's table
+                    sig += " vis=";
+                    for (auto& k : c) sig.push_back(A.visited.get_score({k.node, k.j}, k.st) == TR(k.node, k.j, k.st) ? '1' : '0');
+                    outs += sig + "\n";
+                }
+            }
+            if (bt.node == g.start) break;
+            cur = bt; cst = bst;
+        }
+        if (outs.size() + 1 > cap) outs.resize(cap - 1);
+        std::memcpy(buf, outs.c_str(), outs.size() + 1);
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+// The reference's visited table after one alignment, dense by NODE: M/I/D [node][len+1], UNVISITED = 0xFFFFFFFF.
+extern "C" int oracle_astar_table(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, const uint8_t* seq,
+                                  uint64_t len, uint32_t* pm, uint32_t* pi, uint32_t* pd, uint64_t* out) {
+    auto* h = (GraphHandle*)p;
+    try {
+        Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        AstarResult r = A.astar_alignment(seq, len);
+        const size_t n = h->g.symbol.size(), P = len + 1;
+        for (uint32_t v = 0; v < n; ++v)
+            for (uint32_t j = 0; j <= len; ++j) {
+                pm[v * P + j] = A.visited.get_score({v, j}, ST_M);
+                pi[v * P + j] = A.visited.get_score({v, j}, ST_I);
+                pd[v * P + j] = A.visited.get_score({v, j}, ST_D);
+            }
+        out[0] = r.score; out[1] = r.num_queued; out[2] = r.num_visited; out[3] = r.num_pruned;
+        return 0;
+    } catch (const RefPanic& ex) { g_last_error = ex.what(); return 1; }
+    catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}

@@ -19,7 +19,8 @@ FLAG_AMBIGUOUS, FLAG_START_QUIRK, FLAG_REF_PANIC, FLAG_SHORT_QUERY, FLAG_TRUNCAT
 
 # every symbol include/poasta_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = ["poa_version", "poa_last_error", "poa_device_count", "poa_graph_create", "poa_graph_destroy",
-           "poa_graph_rows", "poa_graph_node_rows", "poa_align_batch", "poa_batch_create", "poa_batch_run",
+           "poa_graph_rows", "poa_graph_node_rows", "poa_align_batch", "poa_align_batch_ex", "poa_batch_create", "poa_batch_run",
+           "poa_batch_run_ex",
            "poa_batch_fetch", "poa_batch_stats", "poa_batch_device_results", "poa_batch_fetch_planes", "poa_batch_destroy"]
 
 
@@ -27,11 +28,20 @@ class PoaCosts(C.Structure):
     _fields_ = [("mismatch", C.c_uint8), ("gap_open", C.c_uint8), ("gap_extend", C.c_uint8), ("reserved", C.c_uint8)]
 
 
+class PoaConfig(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("heuristic", C.c_uint32), ("pruning", C.c_uint32), ("queue_entries_per_cell", C.c_float)]
+
+
+MODE_DENSE, MODE_EXACT, MODE_HYBRID = 0, 1, 2
+HEURISTIC_DIJKSTRA, HEURISTIC_MINGAP = 0, 1
+FLAG_EXACT_OVERFLOW = 0x40
+
+
 class PoaStats(C.Structure):
     _fields_ = [("cells", C.c_uint64), ("bases", C.c_uint64), ("plane_bytes", C.c_uint64), ("n_queries", C.c_uint32),
                 ("n_chunks", C.c_uint32), ("n_forward_launches", C.c_uint32), ("n_flagged", C.c_uint32),
                 ("ms_forward", C.c_float), ("ms_traceback", C.c_float), ("ms_h2d", C.c_float), ("ms_d2h", C.c_float),
-                ("ms_total", C.c_float), ("n_runs", C.c_uint32)]
+                ("ms_exact", C.c_float), ("n_exact", C.c_uint32), ("ms_total", C.c_float), ("n_runs", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ }
@@ -78,6 +88,11 @@ def lib():
     L.poa_align_batch.restype = C.c_int
     L.poa_align_batch.argtypes = [vp, C.POINTER(PoaCosts), C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp,
                                   C.POINTER(PoaStats), C.c_int]
+    L.poa_align_batch_ex.restype = C.c_int
+    L.poa_align_batch_ex.argtypes = [vp, C.POINTER(PoaCosts), C.POINTER(PoaConfig), C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp,
+                                     C.POINTER(PoaStats), C.c_int]
+    L.poa_batch_run_ex.restype = C.c_int
+    L.poa_batch_run_ex.argtypes = [vp, C.POINTER(PoaCosts), C.POINTER(PoaConfig), vp]
     L.poa_batch_create.restype = C.c_int
     L.poa_batch_create.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(vp)]
     L.poa_batch_run.restype = C.c_int

@@ -56,7 +56,8 @@ class AlignmentType:
 
 class AffineMinGapCost:
     """config.rs:104 — the default config of both reference CLIs.  The heuristic only fixes the
-    reference's search order; the dense GPU pass has none."""
+    reference's search order: the dense GPU pass has none, the exact replay emulates it."""
+    heuristic = _lib.HEURISTIC_MINGAP
 
     def __init__(self, costs):
         self.costs = costs
@@ -64,6 +65,17 @@ class AffineMinGapCost:
 
 class AffineDijkstra(AffineMinGapCost):
     """config.rs:49."""
+    heuristic = _lib.HEURISTIC_DIJKSTRA
+
+
+MODES = {"dense": _lib.MODE_DENSE, "exact": _lib.MODE_EXACT, "hybrid": _lib.MODE_HYBRID}
+
+
+def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, queue_entries_per_cell=0.0):
+    """poa_config_t: `mode` "dense" | "exact" (replay the reference's A* for every query: bit-identical
+    tie-breaks) | "hybrid" (replay only the queries the dense pass could not certify)."""
+    return _lib.PoaConfig(MODES[mode] if isinstance(mode, str) else int(mode), int(heuristic), 1 if pruning else 0,
+                          float(queue_entries_per_cell))
 
 
 class AlignedPair:
@@ -175,9 +187,12 @@ class ResidentBatch:
         self.handle = h
         self.pair_capacity = int(self.qoff[-1]) + self.n * self.dg.graph.n
 
-    def run(self, costs, stream=None):
+    def run(self, costs, stream=None, config=None):
         c = costs._c()
-        _lib.check(_lib.lib().poa_batch_run(self.handle, C.byref(c), C.c_void_p(stream or 0)))
+        if config is None:
+            _lib.check(_lib.lib().poa_batch_run(self.handle, C.byref(c), C.c_void_p(stream or 0)))
+        else:
+            _lib.check(_lib.lib().poa_batch_run_ex(self.handle, C.byref(c), C.byref(config), C.c_void_p(stream or 0)))
 
     def fetch(self, want_pairs=True):
         n = self.n
@@ -224,26 +239,27 @@ class ResidentBatch:
 class PoastaAligner:
     """`PoastaAligner::new(config, aln_type)` (mod.rs:53)."""
 
-    def __init__(self, config, aln_type=AlignmentType.Global, device=0):
+    def __init__(self, config, aln_type=AlignmentType.Global, device=0, mode="dense", queue_entries_per_cell=0.0):
         if aln_type != AlignmentType.Global:
             raise NotImplementedError("only AlignmentType::Global runs on the GPU path (SURVEY.md §8(f) row 2)")
         self.config, self.aln_type, self.device = config, aln_type, device
+        self.mode, self.queue_entries_per_cell = mode, queue_entries_per_cell
 
     # -- the three reference entry points; all run the same dense pass ------------------------
-    def align(self, ref_graph, seq):
+    def align(self, ref_graph, seq, pruning=True):
         """mod.rs:114-145."""
-        return self.align_batch(ref_graph, [seq]).result(0)
+        return self.align_batch(ref_graph, [seq], pruning=pruning).result(0)
 
     def align_with_existing_bubbles(self, ref_graph, seq, existing_bubbles=None):
         """mod.rs:69-79.  The bubble index only steers the reference's pruning; unused here."""
         return self.align(ref_graph, seq)
 
     def align_no_pruning(self, ref_graph, seq):
-        """mod.rs:81-90."""
-        return self.align(ref_graph, seq)
+        """mod.rs:81-90 (matters only for the exact replay: no pruning changes which cells the reference visits)."""
+        return self.align(ref_graph, seq, pruning=False)
 
     # -- batch shape (lasagna.rs:246-268) ------------------------------------------------------
-    def align_batch(self, ref_graph, seqs=None, qseq=None, qoff=None, want_pairs=True):
+    def align_batch(self, ref_graph, seqs=None, qseq=None, qoff=None, want_pairs=True, pruning=True):
         dg = _device_graph(ref_graph)
         if seqs is not None:
             qseq, qoff = pack_queries(seqs)
@@ -256,8 +272,9 @@ class PoastaAligner:
         pairs = np.zeros((max(cap, 1), 2), np.uint32) if want_pairs else None
         st = _lib.PoaStats()
         c = self.config.costs._c()
-        _lib.check(_lib.lib().poa_align_batch(dg.handle, C.byref(c), n, _p(qseq), _p(qoff), _p(score), _p(pairs),
-                                              _p(pair_off), cap, _p(flags), C.byref(st), self.device))
+        cfg = make_config(self.mode, self.config.heuristic, pruning, self.queue_entries_per_cell)
+        _lib.check(_lib.lib().poa_align_batch_ex(dg.handle, C.byref(c), C.byref(cfg), n, _p(qseq), _p(qoff), _p(score),
+                                                 _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), self.device))
         if want_pairs:
             pairs = pairs[:int(pair_off[n])]
         return BatchResult(score, pairs, pair_off, flags, st.as_dict())

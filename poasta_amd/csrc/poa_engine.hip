@@ -15,6 +15,7 @@
 
 #include "../../include/poasta_amd.h"
 #include "poa_graph.hpp"
+#include "poa_exact_kernel.hpp"
 #include "poa_kernels.hpp"
 
 using namespace poa_amd;
@@ -72,6 +73,16 @@ struct poa_batch {
     DevBuf<uint64_t> d_qoff, d_plane_off, d_scratch_off, d_pair_off;
     DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
     DevBuf<uint2> d_scratch, d_pairs;
+    // exact-replay mode (allocated on first use)
+    DevBuf<uint32_t> d_succ_off, d_succ_rows, d_dist_min, d_dist_max, d_nbm_off, d_ex_status, d_ex_rcnt, d_ex_head;
+    DevBuf<uint8_t> d_is_exit;
+    DevBuf<FlatGraph::NodeBubble> d_nbm;
+    DevBuf<uint64_t> d_ex_reached;
+    DevBuf<ExQEntry> d_ex_pool;
+    DevBuf<ExStackEntry> d_ex_stack;
+    uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0;
+    bool exact_ready = false;
+    uint32_t last_mode = 0;
 
     // one event set per run since the last stats call: [begin, (fwd_end, tb_end) per chunk..., end]
     std::vector<std::vector<hipEvent_t>> runs;
@@ -94,19 +105,20 @@ static void collect_stats(poa_batch* b, poa_stats_t* stats) {
     stats->n_queries = n; stats->n_chunks = (uint32_t)b->chunks.size();
     stats->n_flagged = keep_flagged;
     stats->ms_h2d = b->ms_h2d; stats->ms_d2h = 0.f;
-    float fwd = 0.f, tb = 0.f, total = 0.f;
+    float fwd = 0.f, tb = 0.f, ex = 0.f, total = 0.f;
     uint32_t launches = 0;
     for (auto& events : b->runs) {
         if (n) {
             size_t ev = 1;
             hipEvent_t prev = events[0];
             for (size_t c = 0; c < b->chunks.size(); ++c) {
-                float a = 0.f, t2 = 0.f;
+                float a = 0.f, t2 = 0.f, t3 = 0.f;
                 (void)hipEventElapsedTime(&a, prev, events[ev]);
                 (void)hipEventElapsedTime(&t2, events[ev], events[ev + 1]);
-                fwd += a; tb += t2;
-                prev = events[ev + 1];
-                ev += 2;
+                (void)hipEventElapsedTime(&t3, events[ev + 1], events[ev + 2]);
+                fwd += a; tb += t2; ex += t3;
+                prev = events[ev + 2];
+                ev += 3;
                 launches++;
             }
             float tail = 0.f, tot = 0.f;
@@ -118,7 +130,7 @@ static void collect_stats(poa_batch* b, poa_stats_t* stats) {
     }
     stats->n_runs = (uint32_t)b->runs.size();
     stats->n_forward_launches = launches;
-    stats->ms_forward = fwd; stats->ms_traceback = tb; stats->ms_total = total;
+    stats->ms_forward = fwd; stats->ms_traceback = tb; stats->ms_exact = ex; stats->ms_total = total;
     for (auto& r : b->runs) b->free_sets.push_back(std::move(r));
     b->runs.clear();
 }
@@ -284,17 +296,75 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     return POA_OK;
 }
 
-int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
+static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_config_t* cfg) {
+    const FlatGraph& fg = b->graph->g;
+    std::string err;
+    int rc = build_bubble_index(const_cast<FlatGraph&>(fg), err);
+    if (rc != POA_OK) return fail(rc, err);
+    const uint32_t n = fg.n;
+    const uint32_t maxc = std::max<uint32_t>(costs->mismatch, (uint32_t)costs->gap_open + costs->gap_extend);
+    const uint64_t n_prio64 = ((uint64_t)n + b->max_len + 2) * maxc + costs->gap_open + ((uint64_t)n + b->max_len) * costs->gap_extend + 64;
+    if (n_prio64 > (1ull << 26)) return fail(POA_ERR_UNSUPPORTED, "exact replay: priority range too large for this graph / query size");
+    const float f = (cfg && cfg->queue_entries_per_cell > 0.f) ? cfg->queue_entries_per_cell : 0.25f;
+    const uint64_t pool64 = std::max<uint64_t>(4096, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
+    if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
+    const uint32_t n_prio = (uint32_t)n_prio64, pool_cap = (uint32_t)pool64;
+    const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64);
+    if (b->exact_ready && b->ex_n_prio >= n_prio && b->ex_pool_cap >= pool_cap) return POA_OK;
+    const uint64_t slots = b->max_chunk;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t need = slots * ((uint64_t)n * wpn * 8 + (uint64_t)n * 4 + 3ull * n_prio * 4 + (uint64_t)stack_cap * 12 + (uint64_t)pool_cap * 16);
+    if (need + (256ull << 20) > free_b + b->d_ex_pool.n * 16 + b->d_ex_head.n * 4 + b->d_ex_reached.n * 8)
+        return fail(POA_ERR_OUT_OF_MEMORY, "exact replay workspace does not fit: create the batch with a smaller workspace_bytes (fewer queries per chunk) or lower queue_entries_per_cell");
+    if (!b->exact_ready) {
+        HIP_TRY(b->d_succ_off.alloc(fg.succ_row_off.size()));
+        HIP_TRY(b->d_succ_rows.alloc(std::max<size_t>(fg.succ_rows.size(), 1)));
+        HIP_TRY(b->d_dist_min.alloc(n)); HIP_TRY(b->d_dist_max.alloc(n)); HIP_TRY(b->d_is_exit.alloc(n));
+        HIP_TRY(b->d_nbm_off.alloc(n + 1)); HIP_TRY(b->d_nbm.alloc(std::max<size_t>(fg.nbm.size(), 1)));
+        HIP_TRY(b->d_ex_status.alloc(std::max<uint32_t>(b->n_queries, 1)));
+        HIP_TRY(hipMemcpy(b->d_succ_off.p, fg.succ_row_off.data(), fg.succ_row_off.size() * 4, hipMemcpyHostToDevice));
+        if (!fg.succ_rows.empty()) HIP_TRY(hipMemcpy(b->d_succ_rows.p, fg.succ_rows.data(), fg.succ_rows.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_dist_min.p, fg.dist_min.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_dist_max.p, fg.dist_max.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_is_exit.p, fg.is_exit.data(), n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_nbm_off.p, fg.nbm_off.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+        if (!fg.nbm.empty()) HIP_TRY(hipMemcpy(b->d_nbm.p, fg.nbm.data(), fg.nbm.size() * sizeof(FlatGraph::NodeBubble), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(b->d_ex_reached.alloc(slots * n * wpn));
+    HIP_TRY(b->d_ex_rcnt.alloc(slots * n));
+    HIP_TRY(b->d_ex_head.alloc(slots * 3 * n_prio));
+    HIP_TRY(b->d_ex_stack.alloc(slots * stack_cap));
+    {
+        hipError_t e = b->d_ex_pool.alloc(slots * pool_cap);
+        if (e != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, std::string("exact replay queue pool: ") + hipGetErrorString(e));
+    }
+    b->ex_n_prio = n_prio; b->ex_pool_cap = pool_cap; b->ex_stack_cap = stack_cap; b->ex_wpn = wpn;
+    b->exact_ready = true;
+    return POA_OK;
+}
+
+int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) { return poa_batch_run_ex(b, costs, nullptr, stream_v); }
+
+int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_t* cfg, void* stream_v) {
     if (!b || !costs) return fail(POA_ERR_INVALID_ARG, "poa_batch_run: null argument");
+    const uint32_t mode = cfg ? cfg->mode : POA_MODE_DENSE;
+    if (mode > POA_MODE_HYBRID) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown mode");
+    if (cfg && cfg->heuristic > POA_HEURISTIC_MINGAP) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown heuristic");
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(b->device));
     const FlatGraph& fg = b->graph->g;
+    if (mode != POA_MODE_DENSE && b->n_queries) {
+        int rc = prepare_exact(b, costs, cfg);
+        if (rc != POA_OK) return rc;
+    }
+    b->last_mode = mode;
     b->last_stream = stream;
     if (b->runs.size() >= 256) return fail(POA_ERR_UNSUPPORTED, "poa_batch_run: call poa_batch_stats/fetch at least every 256 runs");
     std::vector<hipEvent_t> events;
     if (!b->free_sets.empty()) { events = std::move(b->free_sets.back()); b->free_sets.pop_back(); }
     else {
-        events.resize(2 + 2 * b->chunks.size());
+        events.resize(2 + 3 * b->chunks.size());
         for (auto& e : events) HIP_TRY(hipEventCreate(&e));
     }
     b->runs.push_back(events);
@@ -351,9 +421,44 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) {
         tp.score = b->d_score.p; tp.flags = b->d_flags.p; tp.n_pairs = b->d_npairs.p;
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
         tp.spec_depth = spec_depth;
+        tp.exact_pass = 0; tp.ex_status = nullptr;
         if (narrow) hipLaunchKernelGGL(poa_traceback_kernel<uint16_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
         else hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(events[ev++], stream));
+
+        if (mode != POA_MODE_DENSE) {
+            // exact replay of the reference's search on the (re-initialised, u32) planes of this chunk
+            const uint32_t hybrid = mode == POA_MODE_HYBRID ? 1u : 0u;
+            HIP_TRY(hipMemsetAsync(b->d_ex_status.p + ch.first, 0xFF, (size_t)ch.count * 4, stream));
+            hipLaunchKernelGGL(poa_fill_planes_kernel, dim3(64, ch.count), dim3(256), 0, stream, b->d_planes.p, b->d_plane_off.p,
+                               b->d_pitch.p, fg.n, ch.first, hybrid, b->d_flags.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemsetAsync(b->d_ex_reached.p, 0, (size_t)ch.count * fg.n * b->ex_wpn * 8, stream));
+            HIP_TRY(hipMemsetAsync(b->d_ex_rcnt.p, 0, (size_t)ch.count * fg.n * 4, stream));
+            HIP_TRY(hipMemsetAsync(b->d_ex_head.p, 0xFF, (size_t)ch.count * 3 * b->ex_n_prio * 4, stream));
+            ExactParams ep;
+            ep.G = ExactGraph{fg.n, fg.start_row, fg.end_row, b->d_rows.p, b->d_succ_off.p, b->d_succ_rows.p, b->d_dist_min.p,
+                              b->d_dist_max.p, b->d_is_exit.p, b->d_nbm_off.p, b->d_nbm.p};
+            ep.first_query = ch.first; ep.n_queries = ch.count; ep.hybrid = hybrid; ep.dense_flags = b->d_flags.p;
+            ep.qseq = b->d_qseq.p; ep.qoff = b->d_qoff.p; ep.pitch = b->d_pitch.p; ep.plane_off = b->d_plane_off.p;
+            ep.planes = b->d_planes.p;
+            ep.reached = b->d_ex_reached.p; ep.reached_stride = (uint64_t)fg.n * b->ex_wpn; ep.rcnt = b->d_ex_rcnt.p;
+            ep.head = b->d_ex_head.p; ep.n_prio = b->ex_n_prio; ep.pool = b->d_ex_pool.p; ep.pool_cap = b->ex_pool_cap;
+            ep.stack = b->d_ex_stack.p; ep.stack_cap = b->ex_stack_cap;
+            ep.C = ExactCosts{costs->mismatch, costs->gap_open, costs->gap_extend, cfg ? cfg->heuristic : POA_HEURISTIC_MINGAP,
+                              cfg ? cfg->pruning : 1u};
+            ep.status = b->d_ex_status.p;
+            uint32_t lanes = 64;
+            if (const char* lv = getenv("POA_EXACT_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
+            ep.lanes_per_wave = lanes;
+            hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + lanes - 1) / lanes), dim3(64), 0, stream, ep);
+            HIP_TRY(hipGetLastError());
+            tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p;
+            hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            HIP_TRY(hipGetLastError());
+            b->narrow = false;  // the planes now hold the replayed u32 table
+        }
         HIP_TRY(hipEventRecord(events[ev++], stream));
     }
     hipLaunchKernelGGL(poa_scan_kernel, dim3(1), dim3(1024), 0, stream, b->d_npairs.p, b->d_pair_off.p, b->n_queries);
@@ -382,6 +487,7 @@ int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint
     if (!off) { off_local.resize((size_t)n + 1); off = off_local.data(); }
     HIP_TRY(hipMemcpy(off, b->d_pair_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
     int rc = POA_OK;
+    uint32_t n_exact = 0;
     if (n) {
         if (score) HIP_TRY(hipMemcpy(score, b->d_score.p, (size_t)n * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> fl_local;
@@ -397,6 +503,13 @@ int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint
             for (uint32_t i = 0; i < n; ++i) nf += fl[i] != 0;
             stats->n_flagged = nf;
         }
+        if (stats && b->last_mode != POA_MODE_DENSE) {
+            std::vector<uint32_t> stt(n);
+            HIP_TRY(hipMemcpy(stt.data(), b->d_ex_status.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+            uint32_t ne = 0;
+            for (uint32_t i = 0; i < n; ++i) ne += stt[i] == 0;
+            n_exact = ne;
+        }
     } else if (stats) {
         stats->n_flagged = 0;
     }
@@ -409,6 +522,7 @@ int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint
     if (stats) {
         collect_stats(b, stats);
         stats->ms_d2h = ms_d2h;
+        stats->n_exact = n_exact;
     }
     return rc;
 }
@@ -468,6 +582,12 @@ void poa_batch_destroy(poa_batch_t* b) {
 int poa_align_batch(const poa_graph_t* g, const poa_costs_t* costs, uint32_t n_queries, const uint8_t* qseq,
                     const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
                     uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, int device) {
+    return poa_align_batch_ex(g, costs, nullptr, n_queries, qseq, qoff, score, pairs, pair_off, pair_capacity, flags, stats, device);
+}
+
+int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa_config_t* cfg, uint32_t n_queries,
+                       const uint8_t* qseq, const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
+                       uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, int device) {
     if (!g || !costs || !qoff) return fail(POA_ERR_INVALID_ARG, "poa_align_batch: null argument");
     if (stats) std::memset(stats, 0, sizeof(*stats));
     // PoastaAligner::align, empty-graph shortcut (src/aligner/mod.rs:124-142): score 4*len, no pairs
@@ -485,7 +605,7 @@ int poa_align_batch(const poa_graph_t* g, const poa_costs_t* costs, uint32_t n_q
     poa_batch_t* b = nullptr;
     int rc = poa_batch_create(g, device, n_queries, qseq, qoff, 0, &b);
     if (rc != POA_OK) return rc;
-    rc = poa_batch_run(b, costs, nullptr);
+    rc = poa_batch_run_ex(b, costs, cfg, nullptr);
     if (rc == POA_OK) rc = poa_batch_fetch(b, score, pairs, pair_off, pair_capacity, flags, stats);
     poa_batch_destroy(b);
     return rc;

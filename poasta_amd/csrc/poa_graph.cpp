@@ -1,6 +1,8 @@
 #include "poa_graph.hpp"
 
 #include <algorithm>
+#include <deque>
+#include <limits>
 
 #include "../../include/poasta_amd.h"
 
@@ -129,6 +131,146 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
         if (has_end_child || multi) m.flags |= ROW_OPENI_ALWAYS;
         else if (!has_real) m.flags |= ROW_OPENI_NEVER;
     }
+    return POA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The reference's superbubble preprocessing, on node ids, results stored per row.
+int build_bubble_index(FlatGraph& g, std::string& err) {
+    if (g.bubbles_built) return POA_OK;
+    const uint32_t n = g.n;
+    auto succ_of = [&](uint32_t v) { return std::make_pair(g.succ_off[v], g.succ_off[v + 1]); };
+    // successors as rows
+    g.succ_row_off.assign(n + 1, 0);
+    g.succ_rows.clear();
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t v = g.rows[r].node;
+        for (uint32_t e = g.succ_off[v]; e < g.succ_off[v + 1]; ++e) g.succ_rows.push_back(g.node_row[g.succ[e]]);
+        g.succ_row_off[r + 1] = (uint32_t)g.succ_rows.size();
+    }
+    g.dist_min.assign(n, 0); g.dist_max.assign(n, 0); g.is_exit.assign(n, 0);
+    g.nbm_off.assign(n + 1, 0); g.nbm.clear();
+    if (n == 2) { g.bubbles_built = true; return POA_OK; }
+
+    // rev_postorder_nodes (tools.rs:5-37): DFS from start following successors in iteration order
+    std::vector<uint32_t> inv_rpo;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> stack;  // (node, next successor edge)
+        std::vector<uint8_t> visited(n, 0);
+        stack.push_back({g.start, g.succ_off[g.start]});
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            bool pushed = false;
+            while (top.second < g.succ_off[top.first + 1]) {
+                const uint32_t child = g.succ[top.second++];
+                if (!visited[child]) { visited[child] = 1; stack.push_back({child, g.succ_off[child]}); pushed = true; break; }
+            }
+            if (!pushed) { inv_rpo.push_back(stack.back().first); stack.pop_back(); }
+        }
+        std::reverse(inv_rpo.begin(), inv_rpo.end());
+    }
+    if (inv_rpo.size() != n) { err = "bubble index: node unreachable from start"; return POA_ERR_NOT_A_DAG; }
+    std::vector<int64_t> rpo(n, 0);
+    for (uint32_t i = 0; i < n; ++i) rpo[inv_rpo[i]] = i;
+    // finder.rs:37-57
+    std::vector<int64_t> out_parent(n, -1), out_child(n, std::numeric_limits<int64_t>::max());
+    for (uint32_t v = 0; v < n; ++v) {
+        bool any = false; int64_t mn = -1;
+        for (uint32_t e = g.pred_off[v]; e < g.pred_off[v + 1]; ++e) { const int64_t r = rpo[g.pred[e]]; if (!any || r < mn) mn = r; any = true; }
+        out_parent[v] = any ? mn : -1;
+        any = false; int64_t mx = 0;
+        for (uint32_t e = g.succ_off[v]; e < g.succ_off[v + 1]; ++e) { const int64_t r = rpo[g.succ[e]]; if (!any || r > mx) mx = r; any = true; }
+        out_child[v] = any ? mx : std::numeric_limits<int64_t>::max();
+    }
+    // finder.rs:115-178 run to exhaustion
+    std::vector<uint8_t> is_entrance(n, 0), is_exit_node(n, 0);
+    {
+        std::vector<int64_t> opm(n, 0);
+        std::vector<uint8_t> has(n, 0);
+        bool bad = false;
+        auto get = [&](uint32_t k) -> int64_t { if (!has[k]) bad = true; return opm[k]; };
+        auto set = [&](uint32_t k, int64_t v) { opm[k] = v; has[k] = 1; };
+        std::vector<uint32_t> stack;
+        bool have = false; uint32_t cand = 0;
+        auto pop_cand = [&]() { if (stack.empty()) have = false; else { cand = stack.back(); stack.pop_back(); have = true; } };
+        for (uint32_t curr = n; curr-- > 0;) {
+            const uint32_t nn = inv_rpo[curr];
+            const int64_t furthest = out_child[nn];
+            if (furthest == (int64_t)curr + 1) {
+                if (have) stack.push_back(cand);
+                cand = inv_rpo[curr + 1]; have = true;
+            } else {
+                while (have) {
+                    const uint32_t c0 = cand;
+                    if (furthest <= rpo[c0]) break;
+                    pop_cand();
+                    if (have) set(cand, std::min(get(c0), get(cand)));
+                }
+            }
+            if (have) {
+                const uint32_t c0 = cand;
+                if ((uint64_t)get(c0) == (uint64_t)curr) {
+                    is_entrance[nn] = 1; is_exit_node[c0] = 1;
+                    pop_cand();
+                    if (have) set(cand, std::min(get(c0), get(cand)));
+                }
+            }
+            set(nn, out_parent[nn]);
+            if (have) set(cand, std::min(get(nn), get(cand)));
+        }
+        if (bad) { err = "bubble index: superbubble finder read an unset entry (the reference would panic)"; return POA_ERR_UNSUPPORTED; }
+    }
+    // index.rs:73-131: backward BFS from end with the per-path bubble stack
+    std::vector<std::vector<FlatGraph::NodeBubble>> nbm(n);  // exit stored as NODE id here
+    std::vector<uint32_t> dmin(n, 0), dmax(n, 0);
+    {
+        using BStack = std::vector<std::pair<uint32_t, uint32_t>>;  // (dist, exit node)
+        struct Item { uint32_t node, dist; BStack bs; };
+        std::deque<Item> queue;
+        BStack init;
+        if (is_exit_node[g.end]) init.push_back({0u, g.end});
+        queue.push_back({g.end, 0u, init});
+        std::vector<uint8_t> visited(n, 0);
+        visited[g.end] = 1;
+        while (!queue.empty()) {
+            Item it = std::move(queue.front());
+            queue.pop_front();
+            for (auto& b : it.bs) nbm[it.node].push_back({b.second, it.dist - b.first, 0});
+            dmin[it.node] = it.dist;
+            for (uint32_t e = g.pred_off[it.node]; e < g.pred_off[it.node + 1]; ++e) {
+                const uint32_t p = g.pred[e];
+                if (visited[p]) continue;
+                const uint32_t nd = it.dist + 1;
+                BStack nb = it.bs;
+                if (is_entrance[p]) {
+                    if (nb.empty()) { err = "bubble index: empty bubble stack (the reference would panic)"; return POA_ERR_UNSUPPORTED; }
+                    auto top = nb.back(); nb.pop_back();
+                    nbm[p].push_back({top.second, nd - top.first, 0});
+                }
+                if (is_exit_node[p]) nb.push_back({nd, p});
+                visited[p] = 1;
+                queue.push_back({p, nd, std::move(nb)});
+            }
+        }
+    }
+    // index.rs:135-148: longest distance in post-order
+    for (uint32_t i = n; i-- > 0;) {
+        const uint32_t v = inv_rpo[i];
+        uint32_t mx = 0;
+        for (uint32_t e = g.succ_off[v]; e < g.succ_off[v + 1]; ++e) mx = std::max(mx, dmax[g.succ[e]] + 1);
+        dmax[v] = mx;
+        for (auto& b : nbm[v]) b.max_dist = mx - dmax[b.exit_row];
+    }
+    (void)succ_of;
+    for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t v = g.rows[r].node;
+        g.dist_min[r] = dmin[v]; g.dist_max[r] = dmax[v]; g.is_exit[r] = is_exit_node[v];
+        g.nbm_off[r] = (uint32_t)g.nbm.size();
+        for (auto& b : nbm[v]) g.nbm.push_back({g.node_row[b.exit_row], b.min_dist, b.max_dist});
+    }
+    g.nbm_off[n] = (uint32_t)g.nbm.size();
+    g.bubbles_built = true;
     return POA_OK;
 }
 

@@ -40,7 +40,23 @@ struct FlatGraph {
     std::vector<uint32_t> pred_rows;     // predecessors as rows, trait order preserved
     uint32_t start_row = 0, end_row = 0;
     uint32_t max_indegree = 0;
+
+    // ---- exact-replay mode only: the reference's per-graph preprocessing --------------------
+    // successors as rows, trait order preserved (DFA / expand_all iterate them in this order)
+    std::vector<uint32_t> succ_row_off, succ_rows;
+    // BubbleIndex (src/bubbles/index.rs:33-45), indexed by ROW
+    std::vector<uint32_t> dist_min, dist_max;     // dist_to_end (min, max)
+    std::vector<uint8_t> is_exit;                 // bubble_exit[node].is_exit()
+    struct NodeBubble { uint32_t exit_row, min_dist, max_dist; };
+    std::vector<uint32_t> nbm_off;                // [n+1]
+    std::vector<NodeBubble> nbm;                  // node_bubble_map flattened, per-node order preserved
+    bool bubbles_built = false;
 };
+
+// BubbleIndex::new (src/bubbles/index.rs:51-156) over SuperbubbleFinder (src/bubbles/finder.rs:15-178)
+// and rev_postorder_nodes (src/graphs/tools.rs:5-37).  Needed only by the exact-replay mode: it steers
+// the reference's heuristic and pruning and therefore which cells its search visits.
+int build_bubble_index(FlatGraph& g, std::string& err);
 
 // Returns POA_OK or POA_ERR_*; `err` receives a description.
 int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol,

@@ -65,6 +65,10 @@ struct TbParams {
     uint32_t* n_pairs;            // [total]
     uint32_t cost_x, cost_o, cost_e;
     uint32_t spec_depth;          // lanes that speculate per traceback round (1..64)
+    // exact-replay pass: the planes hold the table the replayed search filled; only queries whose
+    // replay succeeded are (re)traced, the others keep their dense result and get a flag.
+    uint32_t exact_pass;
+    const uint32_t* ex_status;    // [total] 0 ok, 1 reference panic, 2 workspace overflow, 0xFFFFFFFF not replayed
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -433,6 +437,14 @@ __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
     const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
     const uint32_t qi = P.first_query + wq;
+    if (P.exact_pass) {
+        const uint32_t stt = P.ex_status[qi];
+        if (stt != 0) {
+            if (lane == 0 && stt == 1) P.flags[qi] |= POA_FLAG_REF_PANIC;
+            if (lane == 0 && stt == 2) P.flags[qi] |= POA_FLAG_EXACT_OVERFLOW;
+            return;
+        }
+    }
     const uint64_t qbeg = P.qoff[qi];
     TbCtx<T> c;
     c.rows = P.rows; c.pred_rows = P.pred_rows;
@@ -553,7 +565,8 @@ __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
     }
     if (!reached_start) flags |= POA_FLAG_TRUNCATED;
     if (lane == 0) {
-        P.flags[qi] = flags;
+        // after an exact replay the table IS the reference's: ties and quirks are resolved exactly as it does
+        P.flags[qi] = P.exact_pass ? (flags & (POA_FLAG_REF_PANIC | POA_FLAG_TRUNCATED)) : flags;
         P.n_pairs[qi] = cnt < cap ? cnt : cap;
     }
 }

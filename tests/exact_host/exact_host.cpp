@@ -1,0 +1,78 @@
+// Test harness (CPU): compiles the PRODUCT's exact-replay search (poasta_amd/csrc/poa_exact.hpp) and
+// graph preprocessing (poa_graph.cpp) for the host so that they can be diffed against the oracle
+// without a GPU.  Not shipped; built by tests/test_exact_replay.py.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/poasta_amd.h"
+#include "../../poasta_amd/csrc/poa_exact.hpp"
+#include "../../poasta_amd/csrc/poa_graph.hpp"
+
+using namespace poa_amd;
+
+extern "C" {
+
+// returns status (EX_*), or negative POA_ERR_* for graph errors.
+// planes (optional): M/I/D as [node][len+1]; out[0..3] = score, num_queued, num_visited, num_pruned
+int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
+                   const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred, uint8_t x, uint8_t o, uint8_t e,
+                   int heuristic, int prune, const uint8_t* seq, uint32_t len, uint32_t* out, uint32_t* pm, uint32_t* pi,
+                   uint32_t* pd) {
+    FlatGraph g;
+    std::string err;
+    int rc = build_flat_graph(n, start, end, symbol, succ_off, succ, pred_off, pred, g, err);
+    if (rc != POA_OK) return rc;
+    rc = build_bubble_index(g, err);
+    if (rc != POA_OK) return rc;
+    ExactGraph G{g.n, g.start_row, g.end_row, g.rows.data(), g.succ_row_off.data(), g.succ_rows.data(),
+                 g.dist_min.data(), g.dist_max.data(), g.is_exit.data(), g.nbm_off.data(), g.nbm.data()};
+    const uint32_t pitch = len + 1, wpn = (len + 1 + 63) / 64;
+    std::vector<uint32_t> M((size_t)n * pitch, EX_INF), I(M), D(M);
+    std::vector<uint64_t> reached((size_t)n * wpn, 0);
+    std::vector<uint32_t> rcnt(n, 0);
+    const uint32_t n_prio = (n + len + 2) * std::max<uint32_t>(x, (uint32_t)o + e) + 2 * ((uint32_t)o + (n + len) * e) + 64;
+    std::vector<uint32_t> head((size_t)3 * n_prio, EX_NIL);
+    std::vector<ExQEntry> pool((size_t)4 * n * pitch + 1024);
+    std::vector<ExStackEntry> stack(n + len + 8);
+    ExactWork W{M.data(), I.data(), D.data(), pitch, reached.data(), rcnt.data(), wpn, head.data(), n_prio,
+                pool.data(), (uint32_t)pool.size(), stack.data(), (uint32_t)stack.size()};
+    ExactSearch S(G, W, seq, len, ExactCosts{x, o, e, (uint32_t)heuristic, (uint32_t)prune});
+    ExactResult R = S.run();
+    out[0] = R.score; out[1] = R.num_queued; out[2] = R.num_visited; out[3] = R.num_pruned;
+    if (pm) {
+        for (uint32_t v = 0; v < n; ++v) {
+            const uint32_t r = g.node_row[v];
+            std::memcpy(pm + (size_t)v * pitch, &M[(size_t)r * pitch], pitch * 4);
+            std::memcpy(pi + (size_t)v * pitch, &I[(size_t)r * pitch], pitch * 4);
+            std::memcpy(pd + (size_t)v * pitch, &D[(size_t)r * pitch], pitch * 4);
+        }
+    }
+    return (int)R.status;
+}
+
+// bubble index of the product side, by NODE: dist (min,max), is_exit, node_bubble_map (exit node, min, max)
+int exact_host_bubbles(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
+                       const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred, uint32_t* dmin, uint32_t* dmax,
+                       uint8_t* is_exit, uint32_t* nbm_off, uint32_t* nbm, uint32_t cap) {
+    FlatGraph g;
+    std::string err;
+    int rc = build_flat_graph(n, start, end, symbol, succ_off, succ, pred_off, pred, g, err);
+    if (rc != POA_OK) return rc;
+    rc = build_bubble_index(g, err);
+    if (rc != POA_OK) return rc;
+    uint32_t k = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+        const uint32_t r = g.node_row[v];
+        dmin[v] = g.dist_min[r]; dmax[v] = g.dist_max[r]; is_exit[v] = g.is_exit[r];
+        nbm_off[v] = k;
+        for (uint32_t i = g.nbm_off[r]; i < g.nbm_off[r + 1]; ++i) {
+            if (k < cap) { nbm[3 * k] = g.rows[g.nbm[i].exit_row].node; nbm[3 * k + 1] = g.nbm[i].min_dist; nbm[3 * k + 2] = g.nbm[i].max_dist; }
+            k++;
+        }
+    }
+    nbm_off[n] = k;
+    return 0;
+}
+}

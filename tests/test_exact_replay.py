@@ -1,0 +1,162 @@
+"""Exact-replay mode (poasta_amd/csrc/poa_exact.hpp): the product's flat restatement of the reference's
+A* search.  CPU: compiled for the host and diffed against the oracle — visited table, score and the
+three search counters must be identical.  GPU: alignments must be bit-identical to the oracle's for
+EVERY query, ties included."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from poasta_amd import workloads as W
+from poasta_amd.graph import pack_queries
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+vp = C.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(vp)
+
+
+@pytest.fixture(scope="module")
+def harness():
+    src = os.path.join(ROOT, "tests", "exact_host", "exact_host.cpp")
+    out = os.path.join(ROOT, "tests", "exact_host", "libexact_host.so")
+    deps = [src] + [os.path.join(ROOT, "poasta_amd", "csrc", f) for f in ("poa_exact.hpp", "poa_graph.cpp", "poa_graph.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
+                               os.path.join(ROOT, "poasta_amd", "csrc", "poa_graph.cpp")])
+    X = C.CDLL(out)
+    X.exact_host_run.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [C.c_uint8] * 3 + [C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]
+    X.exact_host_bubbles.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp] * 5 + [C.c_uint32]
+    return X
+
+
+def _oracle_table(oracle, og, q, costs, heur, prune, n):
+    L = oracle.lib()
+    L.oracle_astar_table.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_int, C.c_int, vp, C.c_uint64, vp, vp, vp, vp]
+    m, i, d = (np.zeros((n, len(q) + 1), np.uint32) for _ in range(3))
+    out = np.zeros(4, np.uint64)
+    rc = L.oracle_astar_table(og.h, *costs, heur, prune, _p(q), len(q), _p(m), _p(i), _p(d), _p(out))
+    return rc, m, i, d, out
+
+
+def _compare(oracle, X, g, qs, costs, heur, prune):
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    n_ok = 0
+    for q in qs:
+        q = np.ascontiguousarray(q, np.uint8)
+        rc1, om, oi, od, oo = _oracle_table(oracle, og, q, costs, heur, prune, g.n)
+        xm, xi, xd = (np.zeros((g.n, len(q) + 1), np.uint32) for _ in range(3))
+        xo = np.zeros(4, np.uint32)
+        rc2 = X.exact_host_run(g.n, g.start, g.end, _p(g.symbol), _p(g.succ_off), _p(g.succ), _p(g.pred_off), _p(g.pred),
+                               *costs, heur, prune, _p(q), len(q), _p(xo), _p(xm), _p(xi), _p(xd))
+        if rc1 == 1 and rc2 == 0:
+            continue  # the oracle's panic came from the BACKTRACE (u32 wrap), which the search does not include
+        assert rc1 == 0 and rc2 == 0, (rc1, rc2)
+        assert oo.tolist() == xo.tolist(), "score / num_queued / num_visited / num_pruned"
+        assert np.array_equal(om, xm) and np.array_equal(oi, xi) and np.array_equal(od, xd), "visited table"
+        n_ok += 1
+    return n_ok
+
+
+def test_product_bubble_index_matches_oracle(oracle, harness):
+    for seed in range(40):
+        g = W.random_dag(seed, n_nodes=12, p_edge=0.3)
+        og = oracle.OracleGraph.from_csr(g.as_dict())
+        bi = og.bubble_index()
+        n = g.n
+        dmin, dmax, ex = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+        off, nbm = np.zeros(n + 1, np.uint32), np.zeros((64 * n, 3), np.uint32)
+        rc = harness.exact_host_bubbles(g.n, g.start, g.end, _p(g.symbol), _p(g.succ_off), _p(g.succ), _p(g.pred_off),
+                                        _p(g.pred), _p(dmin), _p(dmax), _p(ex), _p(off), _p(nbm), 64 * n)
+        assert rc == 0
+        assert list(zip(dmin.tolist(), dmax.tolist())) == bi["dist_to_end"]
+        assert ex.astype(bool).tolist() == bi["is_exit"]
+        for v in range(n):
+            assert [tuple(x) for x in nbm[off[v]:off[v + 1]].tolist()] == bi["node_bubble_map"][v]
+
+
+def test_replay_equals_oracle_search_cpu(oracle, harness):
+    n_ok = 0
+    for seed in range(60):
+        rng = np.random.Generator(np.random.PCG64(1000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, 0.3, alpha) for _ in range(8)]
+        costs = [(4, 6, 2), (2, 8, 1), (1, 10, 2), (3, 1, 1), (4, 4, 2)][seed % 5]
+        for heur, prune in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            n_ok += _compare(oracle, harness, g, qs, costs, heur, prune)
+    assert n_ok > 1500
+    g, (qseq, qoff) = W.scaled_linearish(300, 15, 8, 16, 330)
+    assert _compare(oracle, harness, g, [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(16)], (4, 6, 2), 1, 1) == 16
+    poa = W.LayeredPOA(n_layers=40, width=4, indeg=4, seed=5)
+    assert _compare(oracle, harness, poa.graph, poa.queries(6, length=0), (4, 6, 2), 1, 1) == 6
+    pg = W.PangenomePOA(ref_len=300, n_hap=6, p_snp=0.02, p_indel=0.01, max_indel=6, seed=4)
+    assert _compare(oracle, harness, pg.graph, pg.queries(6, length=120), (4, 6, 2), 1, 1) == 6
+
+
+# ------------------------------------------------------------------------------------------------
+def _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(4, 6, 2), cfg_cls="AffineMinGapCost", pruning=True, mode="exact"):
+    m, o, e = costs
+    al = engine.PoastaAligner(getattr(engine, cfg_cls)(engine.GapAffine(m, e, o)), mode=mode, queue_entries_per_cell=3.0)
+    qseq, qoff = pack_queries(qs)
+    res = al.align_batch(g, qseq=qseq, qoff=qoff, pruning=pruning)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    heur = oracle.H_MINGAP if cfg_cls == "AffineMinGapCost" else oracle.H_DIJKSTRA
+    A = og.astar_batch(qseq, qoff, oracle.Costs(*costs), heur, pruning, threads=4)
+    n = 0
+    for i in range(len(qs)):
+        if A["status"][i] != 0:
+            assert int(res.flags[i]) & 4, "reference panics: REF_PANIC expected"
+            continue
+        assert int(res.score[i]) == int(A["score"][i]), "score, query %d" % i
+        assert res.raw_alignment(i) == oracle.batch_alignment(A, i), "alignment, query %d" % i
+        assert int(res.flags[i]) == 0, "flags, query %d" % i
+        n += 1
+    return n, res
+
+
+@pytest.mark.gpu
+def test_gpu_exact_mode_is_bit_identical(engine, oracle):
+    n = 0
+    for seed in range(40):
+        rng = np.random.Generator(np.random.PCG64(1000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, 0.3, alpha) for _ in range(16)]
+        costs = [(4, 6, 2), (2, 8, 1), (1, 10, 2), (4, 4, 2)][seed % 4]
+        cfg = "AffineMinGapCost" if seed % 3 else "AffineDijkstra"
+        n += _gpu_exact_vs_astar(engine, oracle, g, qs, costs, cfg, pruning=(seed % 5 != 0))[0]
+    assert n > 500
+    g, (qseq, qoff) = W.scaled_linearish(300, 15, 8, 48, 330)
+    assert _gpu_exact_vs_astar(engine, oracle, g, [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(48)])[0] == 48
+    poa = W.LayeredPOA(n_layers=60, width=4, indeg=4, seed=5)
+    assert _gpu_exact_vs_astar(engine, oracle, poa.graph, poa.queries(10, length=0))[0] == 10
+    pg = W.PangenomePOA(ref_len=400, n_hap=6, p_snp=0.02, p_indel=0.01, max_indel=6, seed=4)
+    assert _gpu_exact_vs_astar(engine, oracle, pg.graph, pg.queries(8, length=150))[0] == 8
+
+
+@pytest.mark.gpu
+def test_gpu_exact_config2_sample_and_hybrid(engine, oracle):
+    g, (qseq, qoff) = W.config2(n_queries=96)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(96)]
+    n, res = _gpu_exact_vs_astar(engine, oracle, g, qs)
+    assert n == 96 and res.stats["n_exact"] == 96
+    n, res = _gpu_exact_vs_astar(engine, oracle, g, qs, mode="hybrid")
+    assert n == 96 and res.stats["n_exact"] <= 96
+
+
+@pytest.mark.gpu
+def test_gpu_exact_overflow_keeps_dense_result(engine, oracle):
+    g, (qseq, qoff) = W.scaled_linearish(120, 8, 4, 8, 130)
+    al_d = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 2, 6)))
+    al_x = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 2, 6)), mode="exact", queue_entries_per_cell=1e-6)
+    d = al_d.align_batch(g, qseq=qseq, qoff=qoff)
+    x = al_x.align_batch(g, qseq=qseq, qoff=qoff)
+    for i in range(8):
+        if int(x.flags[i]) & 0x40:  # POA_FLAG_EXACT_OVERFLOW: dense result kept
+            assert int(x.score[i]) == int(d.score[i]) and x.raw_alignment(i) == d.raw_alignment(i)
+    assert any(int(f) & 0x40 for f in x.flags)
