@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Time the exact-replay / hybrid modes on config 2 (GPU box) and check them against the oracle's A*."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as O
+from poasta_amd import aligner, workloads as W
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--queries", type=int, default=2000)
+ap.add_argument("--mode", default="exact")
+ap.add_argument("--check", type=int, default=1)
+args = ap.parse_args()
+g, (qseq, qoff) = W.config2(n_queries=args.queries)
+costs = aligner.GapAffine(4, 2, 6)
+rb = aligner.ResidentBatch(g, qseq, qoff)
+cfg = aligner.make_config(args.mode, queue_entries_per_cell=0.25)
+rb.run(costs, None, cfg); rb.stats()
+t0 = time.time(); rb.run(costs, None, cfg); st = rb.stats(); dt = time.time() - t0
+res = rb.fetch()
+out = dict(mode=args.mode, queries=args.queries, wall_s=round(dt, 4), ms_forward=st["ms_forward"], ms_traceback=st["ms_traceback"],
+           ms_exact=st["ms_exact"], n_exact=res.stats["n_exact"], flagged=int((res.flags != 0).sum()),
+           overflow=int(((res.flags & 0x40) != 0).sum()), lanes=os.environ.get("POA_EXACT_LANES", "64"))
+if args.check:
+    og = O.OracleGraph.from_csr(g.as_dict())
+    A = og.astar_batch(qseq, qoff, O.Costs(4, 6, 2), O.H_MINGAP, True, threads=16)
+    same = sum(res.raw_alignment(i) == O.batch_alignment(A, i) for i in range(args.queries))
+    out.update(score_equal=int((res.score == A["score"]).sum()), alignment_identical=same)
+print(json.dumps(out))
