@@ -306,7 +306,7 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     const uint64_t n_prio64 = ((uint64_t)n + b->max_len + 2) * maxc + costs->gap_open + ((uint64_t)n + b->max_len) * costs->gap_extend + 64;
     if (n_prio64 > (1ull << 26)) return fail(POA_ERR_UNSUPPORTED, "exact replay: priority range too large for this graph / query size");
     const float f = (cfg && cfg->queue_entries_per_cell > 0.f) ? cfg->queue_entries_per_cell : 0.25f;
-    const uint64_t pool64 = std::max<uint64_t>(4096, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
+    const uint64_t pool64 = std::max<uint64_t>(256, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
     if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
     const uint32_t n_prio = (uint32_t)n_prio64, pool_cap = (uint32_t)pool64;
     const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64);
@@ -449,7 +449,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             ep.C = ExactCosts{costs->mismatch, costs->gap_open, costs->gap_extend, cfg ? cfg->heuristic : POA_HEURISTIC_MINGAP,
                               cfg ? cfg->pruning : 1u};
             ep.status = b->d_ex_status.p;
-            uint32_t lanes = 64;
+            // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
+            // waves; enough waves to fill the chip (~20 per CU) first, then more lanes per wave.
+            uint32_t lanes = (ch.count + 4095) / 4096;
+            if (lanes > 64) lanes = 64;
             if (const char* lv = getenv("POA_EXACT_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
             ep.lanes_per_wave = lanes;
             hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + lanes - 1) / lanes), dim3(64), 0, stream, ep);

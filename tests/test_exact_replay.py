@@ -151,7 +151,7 @@ def test_gpu_exact_config2_sample_and_hybrid(engine, oracle):
 
 @pytest.mark.gpu
 def test_gpu_exact_overflow_keeps_dense_result(engine, oracle):
-    g, (qseq, qoff) = W.scaled_linearish(120, 8, 4, 8, 130)
+    g, (qseq, qoff) = W.scaled_linearish(300, 15, 8, 8, 330)
     al_d = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 2, 6)))
     al_x = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 2, 6)), mode="exact", queue_entries_per_cell=1e-6)
     d = al_d.align_batch(g, qseq=qseq, qoff=qoff)
