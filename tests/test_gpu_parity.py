@@ -146,6 +146,19 @@ def test_msa_graph(engine, oracle):
     _check_against_astar(oracle, poa.graph, qs, res)
 
 
+def test_medium_members_of_config4_and_config5(engine, oracle):
+    """BASELINE.json configs[3] / configs[4] graph families at sizes the oracle still finishes in seconds:
+    u32 planes (scores no longer fit u16), multi-predecessor rows everywhere, long rows."""
+    poa = W.LayeredPOA(n_layers=1200, width=4, indeg=4, seed=5)       # 4802 rows, in-degree 4
+    qs = poa.queries(6, length=1500)                                    # 2 strips
+    res, _ = _check_against_dense(engine, oracle, poa.graph, qs)
+    _check_against_astar(oracle, poa.graph, qs, res)
+    pg = W.PangenomePOA(ref_len=4000, n_hap=12, seed=4)                # ~4.1k rows
+    qs = pg.queries(4, length=1500)                                     # 2 strips, Global against the whole graph
+    res, _ = _check_against_dense(engine, oracle, pg.graph, qs)
+    _check_against_astar(oracle, pg.graph, qs, res)
+
+
 def test_config2_sample_vs_astar(engine, oracle):
     """BASELINE.json configs[1] shape, a 64-query sample: every score equals the A* restatement's."""
     g, (qseq, qoff) = W.config2(n_queries=64)
