@@ -383,35 +383,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     b->narrow = narrow;
     uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round)
     if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
+    bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
+    if (const char* fv = getenv("POA_FUSE_TB")) fuse_tb = atoi(fv) != 0;
     int quads_override = 0;
     if (const char* ov = getenv("POA_FWD_QUADS")) quads_override = atoi(ov);  // tuning override
     size_t ev = 1;
     for (const auto& ch : b->chunks) {
-        FwdParams fp;
-        fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
-        fp.first_query = ch.first; fp.n_queries = ch.count;
-        fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = b->d_plane_off.p;
-        fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
-        fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
-        const uint32_t blocks = (ch.count + 3) / 4;
-        uint32_t max_pitch = 0;
-        for (uint32_t i = ch.first; i < ch.first + ch.count; ++i) max_pitch = std::max(max_pitch, b->h_pitch[i]);
-        // strip width: as narrow as the widest plane row of the chunk allows, at most 1024 columns
-        if (narrow) {
-            uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
-            if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
-            if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint16_t>), dim3(blocks), dim3(256), 0, stream, fp);
-            else hipLaunchKernelGGL((poa_forward_kernel<2, uint16_t>), dim3(blocks), dim3(256), 0, stream, fp);
-        } else {
-            uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);  // 256 columns per quad (4 x u32 per lane)
-            if (quads_override == 1 || quads_override == 2 || quads_override == 4) quads = (uint32_t)quads_override;
-            if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint32_t>), dim3(blocks), dim3(256), 0, stream, fp);
-            else if (quads == 2) hipLaunchKernelGGL((poa_forward_kernel<2, uint32_t>), dim3(blocks), dim3(256), 0, stream, fp);
-            else hipLaunchKernelGGL((poa_forward_kernel<4, uint32_t>), dim3(blocks), dim3(256), 0, stream, fp);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(events[ev++], stream));
-
         TbParams tp;
         tp.rows = b->d_rows.p; tp.pred_rows = b->d_pred_rows.p; tp.n_rows = fg.n;
         tp.start_row = fg.start_row; tp.end_row = fg.end_row;
@@ -422,9 +399,41 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
         tp.spec_depth = spec_depth;
         tp.exact_pass = 0; tp.ex_status = nullptr;
-        if (narrow) hipLaunchKernelGGL(poa_traceback_kernel<uint16_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
-        else hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+        FwdParams fp;
+        fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
+        fp.first_query = ch.first; fp.n_queries = ch.count;
+        fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = b->d_plane_off.p;
+        fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
+        fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
+        const uint32_t blocks = (ch.count + 3) / 4;
+#define LAUNCH_FWD(QQ, TT)                                                                                              \
+    do {                                                                                                               \
+        if (fuse_tb) hipLaunchKernelGGL((poa_forward_kernel<QQ, TT, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);  \
+        else hipLaunchKernelGGL((poa_forward_kernel<QQ, TT, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);         \
+    } while (0)
+        uint32_t max_pitch = 0;
+        for (uint32_t i = ch.first; i < ch.first + ch.count; ++i) max_pitch = std::max(max_pitch, b->h_pitch[i]);
+        // strip width: as narrow as the widest plane row of the chunk allows, at most 1024 columns
+        if (narrow) {
+            uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
+            if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
+            if (quads == 1) LAUNCH_FWD(1, uint16_t);
+            else LAUNCH_FWD(2, uint16_t);
+        } else {
+            uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);  // 256 columns per quad (4 x u32 per lane)
+            if (quads_override == 1 || quads_override == 2 || quads_override == 4) quads = (uint32_t)quads_override;
+            if (quads == 1) LAUNCH_FWD(1, uint32_t);
+            else if (quads == 2) LAUNCH_FWD(2, uint32_t);
+            else LAUNCH_FWD(4, uint32_t);
+        }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(events[ev++], stream));
+
+        if (!fuse_tb) {
+            if (narrow) hipLaunchKernelGGL(poa_traceback_kernel<uint16_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            else hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
         if (mode != POA_MODE_DENSE) {

@@ -137,6 +137,259 @@ template <> struct PlaneIO<uint16_t> {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Traceback: the reference's score-based rule (scoring/gap_affine.rs:550-657, :804-915) applied to
+// the dense planes.  Every test of a step is evaluated so that the certificate "exactly one
+// candidate, no phantom below target" can be decided (DESIGN.md §4).  One thread per query.
+template <typename T>
+struct TbCtx {
+    const RowMeta* rows;
+    const uint32_t* pred_rows;
+    const T* M;
+    const T* I;
+    const T* D;
+    const uint8_t* q;
+    uint32_t L, pitch, start_row, end_row;
+    uint32_t x, o, e;
+};
+
+struct TbStep {
+    uint32_t row, j, st;  // st: 0 M, 1 D, 2 I
+    bool found;
+};
+
+template <typename T>
+__device__ __forceinline__ uint32_t pl(const T* p, uint32_t pitch, uint32_t row, uint32_t j) {
+    return PlaneIO<T>::get(p + (uint64_t)row * pitch + j);
+}
+
+template <typename T>
+__device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j) {
+    if (j >= c.L) return false;
+    if (m.flags & ROW_OPENI_ALWAYS) return true;
+    if (m.flags & ROW_OPENI_NEVER) return false;
+    return (uint32_t)m.child_sym != (uint32_t)c.q[j];
+}
+
+template <typename T>
+__device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st, uint32_t& n_cand,
+                                 bool& bad, bool& panic) {
+    TbStep first{0, 0, 0, false};
+    n_cand = 0;
+    const RowMeta m = c.rows[row];
+    const bool is_end = (m.flags & ROW_END) != 0;
+    auto sub = [&](uint32_t a, uint32_t b) { uint32_t r = a - b; if (r == INF) panic = true; return r; };
+    auto cand = [&](uint32_t r2, uint32_t j2, uint32_t s2) {
+        if (!first.found) first = TbStep{r2, j2, s2, true};
+        n_cand++;
+    };
+    if (st == 0) {
+        // all loads of the step are issued before the first use (one memory round-trip for chain rows)
+        const uint32_t cs = pl(c.M, c.pitch, row, j);
+        const uint32_t dv = pl(c.D, c.pitch, row, j);
+        const uint32_t iv = pl(c.I, c.pitch, row, j);
+        const uint32_t up = (row > 0 && j > 0) ? pl(c.M, c.pitch, row - 1, j - 1) : INF;  // the usual diagonal predecessor
+        if (cs == INF) return first;
+        if (j > 0) {
+            const bool moe = is_end || ((uint32_t)m.sym == (uint32_t)c.q[j - 1]);
+            const uint32_t pj = is_end ? j : j - 1;
+            const uint32_t target = moe ? cs : sub(cs, c.x);
+            if ((m.flags & ROW_CHAIN) && !is_end) {  // the end row reads its predecessor at the SAME column
+                if (up == target) cand(row - 1, pj, 0);
+            } else {
+                for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+                    const uint32_t pr = c.pred_rows[m.pred_begin + pe];
+                    if (pl(c.M, c.pitch, pr, pj) == target) cand(pr, pj, 0);
+                }
+            }
+        }
+        if (dv == cs) cand(row, j, 1);
+        if (iv == cs) cand(row, j, 2);
+    } else if (st == 1) {
+        const uint32_t cs = pl(c.D, c.pitch, row, j);
+        if (cs == INF) return first;
+        if (m.pred_count == 0) return first;
+        const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
+        const bool real_open = !is_end && (j >= c.L || (uint32_t)m.sym != (uint32_t)c.q[j]);
+        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+            const uint32_t pr = c.pred_rows[m.pred_begin + pe];
+            const uint32_t ps = pl(c.M, c.pitch, pr, j);
+            if (ps == t_open) cand(pr, j, 0);
+            else if (!real_open && ps < t_open) bad = true;  // phantom edge the reference does not re-check
+        }
+        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+            const uint32_t pr = c.pred_rows[m.pred_begin + pe];
+            if (pl(c.D, c.pitch, pr, j) == t_ext) cand(pr, j, 1);
+        }
+    } else {
+        const uint32_t cs = pl(c.I, c.pitch, row, j);
+        if (cs == INF) return first;
+        if (j > 0) {
+            const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
+            const uint32_t pm = pl(c.M, c.pitch, row, j - 1);
+            const uint32_t pi = pl(c.I, c.pitch, row, j - 1);
+            if (pm == t_open) cand(row, j - 1, 0);
+            else if (!tb_open_i(c, m, j - 1) && pm < t_open) bad = true;
+            if (pi == t_ext) {
+                const bool only = (n_cand == 0);
+                cand(row, j - 1, 0);  // sic: the reference returns Match here (gap_affine.rs:649)
+                if (only && pm != pi) bad = true;  // the hop lands on M[row][j-1] which is not this I value
+            }
+        }
+    }
+    return first;
+}
+
+// One WAVE per query.  A traceback is a chain of dependent reads (~2 us each from HBM): to cut the
+// chain, lane i speculatively evaluates the step at cell (row - i, j - i) — where the path is if
+// the previous i steps were all (mis)match steps to the previous row — and the longest prefix of
+// lanes whose step really is that diagonal move is accepted at once.  The first lane that deviates
+// (gap open/close, bubble predecessor, start reached) is then handled exactly like the sequential
+// rule, so the emitted alignment and flags are identical to a step-by-step walk.
+template <typename T>
+__device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t qi, const uint32_t lane) {
+    if (P.exact_pass) {
+        const uint32_t stt = P.ex_status[qi];
+        if (stt != 0) {
+            if (lane == 0 && stt == 1) P.flags[qi] |= POA_FLAG_REF_PANIC;
+            if (lane == 0 && stt == 2) P.flags[qi] |= POA_FLAG_EXACT_OVERFLOW;
+            return;
+        }
+    }
+    const uint64_t qbeg = P.qoff[qi];
+    TbCtx<T> c;
+    c.rows = P.rows; c.pred_rows = P.pred_rows;
+    c.L = (uint32_t)(P.qoff[qi + 1] - qbeg);
+    c.q = P.qseq + qbeg;
+    c.pitch = P.pitch[qi];
+    const uint64_t RP = (uint64_t)P.n_rows * c.pitch;
+    c.M = reinterpret_cast<const T*>(P.planes) + P.plane_off[qi];
+    c.I = c.M + RP;
+    c.D = c.I + RP;
+    c.start_row = P.start_row; c.end_row = P.end_row;
+    c.x = P.cost_x; c.o = P.cost_o; c.e = P.cost_e;
+    const uint32_t L = c.L;
+
+    uint2* out = P.scratch + P.scratch_off[qi];
+    const uint32_t cap = (uint32_t)(P.scratch_off[qi + 1] - P.scratch_off[qi]);
+    uint32_t cnt = 0;    // wave-uniform
+    uint32_t flags = 0;  // wave-uniform
+    auto emit_at = [&](uint32_t pos, uint32_t rpos, uint32_t qpos) {
+        if (pos < cap) out[cap - 1 - pos] = make_uint2(rpos, qpos);
+    };
+    auto bc = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); };
+
+    if (lane == 0) P.score[qi] = pl(c.M, c.pitch, c.end_row, L);
+    const uint32_t end_node = c.rows[c.end_row].node;
+
+    bool done = false;
+    uint32_t crow = 0, cj = 0, cst = 0;
+    if (L == 0) done = true;
+    if (!done && L == 1) {
+        // gap_affine.rs:812-824: the end node equals every symbol -> always [(end, 0)]
+        flags |= POA_FLAG_SHORT_QUERY;
+        if (lane == 0) emit_at(0, end_node, 0);
+        cnt = 1;
+        done = true;
+    }
+    if (!done) {
+        // first hop from the end cell: Match, .or_else(Insertion), .or_else(Deletion) (gap_affine.rs:832-835)
+        uint32_t f0 = 0, fr = 0, fj = 0, fs = 0, fallback = 0;
+        if (lane == 0) {
+            uint32_t nc; bool bad = false, pn = false;
+            TbStep cur = tb_step(c, c.end_row, L, 0, nc, bad, pn);
+            if (pn) f0 |= POA_FLAG_REF_PANIC;
+            if (cur.found && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
+            if (!cur.found) {
+                cur = tb_step(c, c.end_row, L, 2, nc, bad, pn);
+                if (!cur.found) cur = tb_step(c, c.end_row, L, 1, nc, bad, pn);
+                if (!cur.found) { f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
+                else f0 |= POA_FLAG_AMBIGUOUS;
+            }
+            fr = cur.row; fj = cur.j; fs = cur.st;
+        }
+        flags |= bc(f0, 0);
+        if (bc(fallback, 0)) {
+            if (L <= 3) {
+                if (lane == 0) for (uint32_t i = 0; i < L; ++i) emit_at(i, end_node, L - 1 - i);
+                cnt = L;
+            }
+            done = true;
+        } else {
+            crow = bc(fr, 0); cj = bc(fj, 0); cst = bc(fs, 0);
+        }
+    }
+    bool reached_start = done;  // nothing to truncate in the special cases
+    while (!done) {
+        uint32_t depth = 1;
+        if (cst == 0) {
+            depth = P.spec_depth;
+            if (crow + 1 < depth) depth = crow + 1;
+            if (cj + 1 < depth) depth = cj + 1;
+        }
+        const bool active = lane < depth;
+        const uint32_t my_row = crow - lane, my_j = cj - lane;
+        TbStep bt{0, 0, 0, false};
+        uint32_t nc = 0;
+        bool bad = false, pn = false;
+        if (active) bt = tb_step(c, my_row, my_j, cst, nc, bad, pn);
+        const bool amb = active && bt.found && (nc != 1 || bad);
+        const bool quirk = active && bt.found && bt.st == 0 && bt.j == 0 && bt.row != c.start_row && cst != 1 &&
+                           (uint32_t)c.rows[bt.row].sym == (uint32_t)c.q[0];
+        // a "regular" step: (mis)match into exactly the cell the next lane speculated on, not yet at start
+        const bool regular = active && cst == 0 && bt.found && bt.st == 0 && bt.row + 1 == my_row &&
+                             bt.j + 1 == my_j && bt.row != c.start_row;
+        const uint64_t rb = __ballot(regular);
+        const uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
+        const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
+        if (__ballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
+        if (__ballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
+        if (__ballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
+        if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, my_j - 1);
+        cnt += p;
+        if (p == depth) {
+            // every speculated step was regular: continue below the last one
+            crow -= depth; cj -= depth;  // state stays Match
+            continue;
+        }
+        // lane p deviates: replay the sequential rule with its results
+        const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
+        const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_pn = bc(pn ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
+        const uint32_t cur_row = crow - p, cur_j = cj - p, cur_st = (p == 0) ? cst : 0u;
+        if (d_pn) flags |= POA_FLAG_REF_PANIC;
+        if (!d_found) break;
+        if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
+        if (cur_st == 0 && d_st != 0) {  // zero-cost gap close: no pair (gap_affine.rs:871-875)
+            crow = d_row; cj = d_j; cst = d_st;
+            continue;
+        }
+        if (lane == 0) {
+            const uint32_t node = c.rows[cur_row].node;
+            if (cur_st == 0) emit_at(cnt, node, cur_j - 1);
+            else if (cur_st == 2) emit_at(cnt, POA_NONE, cur_j - 1);
+            else emit_at(cnt, node, POA_NONE);
+        }
+        cnt += 1;
+        if (d_quirk) flags |= POA_FLAG_START_QUIRK;
+        if (d_row == c.start_row) { reached_start = true; break; }
+        crow = d_row; cj = d_j; cst = d_st;
+    }
+    if (!reached_start) flags |= POA_FLAG_TRUNCATED;
+    if (lane == 0) {
+        // after an exact replay the table IS the reference's: ties and quirks are resolved exactly as it does
+        P.flags[qi] = P.exact_pass ? (flags & (POA_FLAG_REF_PANIC | POA_FLAG_TRUNCATED)) : flags;
+        P.n_pairs[qi] = cnt < cap ? cnt : cap;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    if (wq >= P.n_queries) return;
+    traceback_wave<T>(P, P.first_query + wq, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward pass.  One wave per query; 4 waves (queries) per 256-thread block.
 //
 // Layout ("quad-striped"): a strip is W = Q*64*K columns; lane l owns, in each of the Q quads,
@@ -144,8 +397,10 @@ template <> struct PlaneIO<uint16_t> {
 // global_load/store_dwordx4 of a quad therefore covers 1 KiB contiguous bytes per wave-instruction
 // (8 full 128-B lines), the quads' insertion scans are independent chains, and the column-(j-1)
 // neighbour is an in-register value except for k = 0 (one DPP wave_shr:1 per quad).
-template <int Q, typename T>
-__global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
+// FUSE_TB: the wave traces its own query right after its last row (the latency-bound traceback then overlaps
+// other waves' HBM-bound forward work instead of running as a separate launch).
+template <int Q, typename T, bool FUSE_TB>
+__global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams TP) {
     using IO = PlaneIO<T>;
     constexpr int K = IO::K;
     constexpr int C = K * Q;
@@ -320,256 +575,12 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P) {
         }
         if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // carry[] and edge columns for the next strip
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Traceback: the reference's score-based rule (scoring/gap_affine.rs:550-657, :804-915) applied to
-// the dense planes.  Every test of a step is evaluated so that the certificate "exactly one
-// candidate, no phantom below target" can be decided (DESIGN.md §4).  One thread per query.
-template <typename T>
-struct TbCtx {
-    const RowMeta* rows;
-    const uint32_t* pred_rows;
-    const T* M;
-    const T* I;
-    const T* D;
-    const uint8_t* q;
-    uint32_t L, pitch, start_row, end_row;
-    uint32_t x, o, e;
-};
-
-struct TbStep {
-    uint32_t row, j, st;  // st: 0 M, 1 D, 2 I
-    bool found;
-};
-
-template <typename T>
-__device__ __forceinline__ uint32_t pl(const T* p, uint32_t pitch, uint32_t row, uint32_t j) {
-    return PlaneIO<T>::get(p + (uint64_t)row * pitch + j);
-}
-
-template <typename T>
-__device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j) {
-    if (j >= c.L) return false;
-    if (m.flags & ROW_OPENI_ALWAYS) return true;
-    if (m.flags & ROW_OPENI_NEVER) return false;
-    return (uint32_t)m.child_sym != (uint32_t)c.q[j];
-}
-
-template <typename T>
-__device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st, uint32_t& n_cand,
-                                 bool& bad, bool& panic) {
-    TbStep first{0, 0, 0, false};
-    n_cand = 0;
-    const RowMeta m = c.rows[row];
-    const bool is_end = (m.flags & ROW_END) != 0;
-    auto sub = [&](uint32_t a, uint32_t b) { uint32_t r = a - b; if (r == INF) panic = true; return r; };
-    auto cand = [&](uint32_t r2, uint32_t j2, uint32_t s2) {
-        if (!first.found) first = TbStep{r2, j2, s2, true};
-        n_cand++;
-    };
-    if (st == 0) {
-        // all loads of the step are issued before the first use (one memory round-trip for chain rows)
-        const uint32_t cs = pl(c.M, c.pitch, row, j);
-        const uint32_t dv = pl(c.D, c.pitch, row, j);
-        const uint32_t iv = pl(c.I, c.pitch, row, j);
-        const uint32_t up = (row > 0 && j > 0) ? pl(c.M, c.pitch, row - 1, j - 1) : INF;  // the usual diagonal predecessor
-        if (cs == INF) return first;
-        if (j > 0) {
-            const bool moe = is_end || ((uint32_t)m.sym == (uint32_t)c.q[j - 1]);
-            const uint32_t pj = is_end ? j : j - 1;
-            const uint32_t target = moe ? cs : sub(cs, c.x);
-            if ((m.flags & ROW_CHAIN) && !is_end) {  // the end row reads its predecessor at the SAME column
-                if (up == target) cand(row - 1, pj, 0);
-            } else {
-                for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-                    const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-                    if (pl(c.M, c.pitch, pr, pj) == target) cand(pr, pj, 0);
-                }
-            }
-        }
-        if (dv == cs) cand(row, j, 1);
-        if (iv == cs) cand(row, j, 2);
-    } else if (st == 1) {
-        const uint32_t cs = pl(c.D, c.pitch, row, j);
-        if (cs == INF) return first;
-        if (m.pred_count == 0) return first;
-        const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
-        const bool real_open = !is_end && (j >= c.L || (uint32_t)m.sym != (uint32_t)c.q[j]);
-        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-            const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-            const uint32_t ps = pl(c.M, c.pitch, pr, j);
-            if (ps == t_open) cand(pr, j, 0);
-            else if (!real_open && ps < t_open) bad = true;  // phantom edge the reference does not re-check
-        }
-        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-            const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-            if (pl(c.D, c.pitch, pr, j) == t_ext) cand(pr, j, 1);
-        }
-    } else {
-        const uint32_t cs = pl(c.I, c.pitch, row, j);
-        if (cs == INF) return first;
-        if (j > 0) {
-            const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
-            const uint32_t pm = pl(c.M, c.pitch, row, j - 1);
-            const uint32_t pi = pl(c.I, c.pitch, row, j - 1);
-            if (pm == t_open) cand(row, j - 1, 0);
-            else if (!tb_open_i(c, m, j - 1) && pm < t_open) bad = true;
-            if (pi == t_ext) {
-                const bool only = (n_cand == 0);
-                cand(row, j - 1, 0);  // sic: the reference returns Match here (gap_affine.rs:649)
-                if (only && pm != pi) bad = true;  // the hop lands on M[row][j-1] which is not this I value
-            }
-        }
-    }
-    return first;
-}
-
-// One WAVE per query.  A traceback is a chain of dependent reads (~2 us each from HBM): to cut the
-// chain, lane i speculatively evaluates the step at cell (row - i, j - i) — where the path is if
-// the previous i steps were all (mis)match steps to the previous row — and the longest prefix of
-// lanes whose step really is that diagonal move is accepted at once.  The first lane that deviates
-// (gap open/close, bubble predecessor, start reached) is then handled exactly like the sequential
-// rule, so the emitted alignment and flags are identical to a step-by-step walk.
-template <typename T>
-__global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
-    if (wq >= P.n_queries) return;
-    const uint32_t qi = P.first_query + wq;
-    if (P.exact_pass) {
-        const uint32_t stt = P.ex_status[qi];
-        if (stt != 0) {
-            if (lane == 0 && stt == 1) P.flags[qi] |= POA_FLAG_REF_PANIC;
-            if (lane == 0 && stt == 2) P.flags[qi] |= POA_FLAG_EXACT_OVERFLOW;
-            return;
-        }
-    }
-    const uint64_t qbeg = P.qoff[qi];
-    TbCtx<T> c;
-    c.rows = P.rows; c.pred_rows = P.pred_rows;
-    c.L = (uint32_t)(P.qoff[qi + 1] - qbeg);
-    c.q = P.qseq + qbeg;
-    c.pitch = P.pitch[qi];
-    const uint64_t RP = (uint64_t)P.n_rows * c.pitch;
-    c.M = reinterpret_cast<const T*>(P.planes) + P.plane_off[qi];
-    c.I = c.M + RP;
-    c.D = c.I + RP;
-    c.start_row = P.start_row; c.end_row = P.end_row;
-    c.x = P.cost_x; c.o = P.cost_o; c.e = P.cost_e;
-    const uint32_t L = c.L;
-
-    uint2* out = P.scratch + P.scratch_off[qi];
-    const uint32_t cap = (uint32_t)(P.scratch_off[qi + 1] - P.scratch_off[qi]);
-    uint32_t cnt = 0;    // wave-uniform
-    uint32_t flags = 0;  // wave-uniform
-    auto emit_at = [&](uint32_t pos, uint32_t rpos, uint32_t qpos) {
-        if (pos < cap) out[cap - 1 - pos] = make_uint2(rpos, qpos);
-    };
-    auto bc = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); };
-
-    if (lane == 0) P.score[qi] = pl(c.M, c.pitch, c.end_row, L);
-    const uint32_t end_node = c.rows[c.end_row].node;
-
-    bool done = false;
-    uint32_t crow = 0, cj = 0, cst = 0;
-    if (L == 0) done = true;
-    if (!done && L == 1) {
-        // gap_affine.rs:812-824: the end node equals every symbol -> always [(end, 0)]
-        flags |= POA_FLAG_SHORT_QUERY;
-        if (lane == 0) emit_at(0, end_node, 0);
-        cnt = 1;
-        done = true;
-    }
-    if (!done) {
-        // first hop from the end cell: Match, .or_else(Insertion), .or_else(Deletion) (gap_affine.rs:832-835)
-        uint32_t f0 = 0, fr = 0, fj = 0, fs = 0, fallback = 0;
-        if (lane == 0) {
-            uint32_t nc; bool bad = false, pn = false;
-            TbStep cur = tb_step(c, c.end_row, L, 0, nc, bad, pn);
-            if (pn) f0 |= POA_FLAG_REF_PANIC;
-            if (cur.found && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
-            if (!cur.found) {
-                cur = tb_step(c, c.end_row, L, 2, nc, bad, pn);
-                if (!cur.found) cur = tb_step(c, c.end_row, L, 1, nc, bad, pn);
-                if (!cur.found) { f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
-                else f0 |= POA_FLAG_AMBIGUOUS;
-            }
-            fr = cur.row; fj = cur.j; fs = cur.st;
-        }
-        flags |= bc(f0, 0);
-        if (bc(fallback, 0)) {
-            if (L <= 3) {
-                if (lane == 0) for (uint32_t i = 0; i < L; ++i) emit_at(i, end_node, L - 1 - i);
-                cnt = L;
-            }
-            done = true;
-        } else {
-            crow = bc(fr, 0); cj = bc(fj, 0); cst = bc(fs, 0);
-        }
-    }
-    bool reached_start = done;  // nothing to truncate in the special cases
-    while (!done) {
-        uint32_t depth = 1;
-        if (cst == 0) {
-            depth = P.spec_depth;
-            if (crow + 1 < depth) depth = crow + 1;
-            if (cj + 1 < depth) depth = cj + 1;
-        }
-        const bool active = lane < depth;
-        const uint32_t my_row = crow - lane, my_j = cj - lane;
-        TbStep bt{0, 0, 0, false};
-        uint32_t nc = 0;
-        bool bad = false, pn = false;
-        if (active) bt = tb_step(c, my_row, my_j, cst, nc, bad, pn);
-        const bool amb = active && bt.found && (nc != 1 || bad);
-        const bool quirk = active && bt.found && bt.st == 0 && bt.j == 0 && bt.row != c.start_row && cst != 1 &&
-                           (uint32_t)c.rows[bt.row].sym == (uint32_t)c.q[0];
-        // a "regular" step: (mis)match into exactly the cell the next lane speculated on, not yet at start
-        const bool regular = active && cst == 0 && bt.found && bt.st == 0 && bt.row + 1 == my_row &&
-                             bt.j + 1 == my_j && bt.row != c.start_row;
-        const uint64_t rb = __ballot(regular);
-        const uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
-        const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
-        if (__ballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
-        if (__ballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
-        if (__ballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
-        if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, my_j - 1);
-        cnt += p;
-        if (p == depth) {
-            // every speculated step was regular: continue below the last one
-            crow -= depth; cj -= depth;  // state stays Match
-            continue;
-        }
-        // lane p deviates: replay the sequential rule with its results
-        const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
-        const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_pn = bc(pn ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
-        const uint32_t cur_row = crow - p, cur_j = cj - p, cur_st = (p == 0) ? cst : 0u;
-        if (d_pn) flags |= POA_FLAG_REF_PANIC;
-        if (!d_found) break;
-        if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
-        if (cur_st == 0 && d_st != 0) {  // zero-cost gap close: no pair (gap_affine.rs:871-875)
-            crow = d_row; cj = d_j; cst = d_st;
-            continue;
-        }
-        if (lane == 0) {
-            const uint32_t node = c.rows[cur_row].node;
-            if (cur_st == 0) emit_at(cnt, node, cur_j - 1);
-            else if (cur_st == 2) emit_at(cnt, POA_NONE, cur_j - 1);
-            else emit_at(cnt, node, POA_NONE);
-        }
-        cnt += 1;
-        if (d_quirk) flags |= POA_FLAG_START_QUIRK;
-        if (d_row == c.start_row) { reached_start = true; break; }
-        crow = d_row; cj = d_j; cst = d_st;
-    }
-    if (!reached_start) flags |= POA_FLAG_TRUNCATED;
-    if (lane == 0) {
-        // after an exact replay the table IS the reference's: ties and quirks are resolved exactly as it does
-        P.flags[qi] = P.exact_pass ? (flags & (POA_FLAG_REF_PANIC | POA_FLAG_TRUNCATED)) : flags;
-        P.n_pairs[qi] = cnt < cap ? cnt : cap;
+    if (FUSE_TB) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // my plane stores are complete before I read them back
+        traceback_wave<T>(TP, qi, lane);
     }
 }
+
 
 // exclusive prefix sum of n_pairs -> pair_off[n+1]; single block.
 __global__ __launch_bounds__(1024) void poa_scan_kernel(const uint32_t* __restrict__ n_pairs, uint64_t* __restrict__ pair_off,
