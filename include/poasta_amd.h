@@ -72,7 +72,10 @@ typedef struct poa_config {
     uint32_t heuristic;       /* POA_HEURISTIC_* (replay only) */
     uint32_t pruning;         /* 1: align / align_with_existing_bubbles; 0: align_no_pruning (mod.rs:81-90) */
     float queue_entries_per_cell; /* replay queue pool, entries per (row x column) cell; 0 = default 0.25 */
+    uint32_t flags;           /* POA_CFG_* */
 } poa_config_t;
+#define POA_CFG_FULL_PLANES 1u /* keep all three score planes in memory (needed by poa_batch_fetch_planes); the default
+                                  u16 layout stores M, a 4-bit code per cell instead of I, and only the D rows read back */
 
 /* AlignedPair (alignment.rs:4-13): rpos = node index of the host graph, qpos = 0-based query position */
 typedef struct poa_aln_pair {

@@ -181,7 +181,7 @@ public:
         std::vector<uint64_t> pair_off(n + 1, 0);
         std::vector<poa_aln_pair_t> pairs(cap);
         const poa_costs_t c{config_.costs.mismatch(), config_.costs.gap_open(), config_.costs.gap_extend(), 0};
-        const poa_config_t cfg{(uint32_t)mode_, Config::heuristic, pruning ? 1u : 0u, 0.f};
+        const poa_config_t cfg{(uint32_t)mode_, Config::heuristic, pruning ? 1u : 0u, 0.f, 0u};
         const int rc = poa_align_batch_ex(g.device_graph(), &c, &cfg, n, (const uint8_t*)qseq.data(), qoff.data(), score.data(),
                                           pairs.data(), pair_off.data(), cap, flags.data(), stats, device_);
         if (rc != POA_OK) throw PoastaError(std::string("poa_align_batch: ") + poa_last_error());

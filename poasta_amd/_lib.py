@@ -29,12 +29,14 @@ class PoaCosts(C.Structure):
 
 
 class PoaConfig(C.Structure):
-    _fields_ = [("mode", C.c_uint32), ("heuristic", C.c_uint32), ("pruning", C.c_uint32), ("queue_entries_per_cell", C.c_float)]
+    _fields_ = [("mode", C.c_uint32), ("heuristic", C.c_uint32), ("pruning", C.c_uint32), ("queue_entries_per_cell", C.c_float),
+                ("flags", C.c_uint32)]
 
 
 MODE_DENSE, MODE_EXACT, MODE_HYBRID = 0, 1, 2
 HEURISTIC_DIJKSTRA, HEURISTIC_MINGAP = 0, 1
 FLAG_EXACT_OVERFLOW = 0x40
+CFG_FULL_PLANES = 1
 
 
 class PoaStats(C.Structure):

@@ -71,11 +71,11 @@ class AffineDijkstra(AffineMinGapCost):
 MODES = {"dense": _lib.MODE_DENSE, "exact": _lib.MODE_EXACT, "hybrid": _lib.MODE_HYBRID}
 
 
-def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, queue_entries_per_cell=0.0):
+def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, queue_entries_per_cell=0.0, full_planes=False):
     """poa_config_t: `mode` "dense" | "exact" (replay the reference's A* for every query: bit-identical
     tie-breaks) | "hybrid" (replay only the queries the dense pass could not certify)."""
     return _lib.PoaConfig(MODES[mode] if isinstance(mode, str) else int(mode), int(heuristic), 1 if pruning else 0,
-                          float(queue_entries_per_cell))
+                          float(queue_entries_per_cell), _lib.CFG_FULL_PLANES if full_planes else 0)
 
 
 class AlignedPair:

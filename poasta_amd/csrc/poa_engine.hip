@@ -65,6 +65,7 @@ struct poa_batch {
     uint32_t max_chunk = 0;
     uint64_t max_len = 0;
     bool narrow = false;  // last run used u16 planes
+    bool compact = false; // last run used the compact layout (no I plane, partial D)
     int cols_per_lane = 16;
 
     DevBuf<RowMeta> d_rows;
@@ -266,7 +267,7 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(b->d_npairs.alloc(std::max<uint32_t>(n_queries, 1)));
     HIP_TRY(b->d_scratch.alloc(std::max<uint64_t>(scratch_total, 1)));
     HIP_TRY(b->d_pairs.alloc(std::max<uint64_t>(scratch_total, 1)));
-    HIP_TRY(b->d_carry.alloc(std::max<uint64_t>((uint64_t)b->max_chunk * rows, 1)));
+    HIP_TRY(b->d_carry.alloc(std::max<uint64_t>(2ull * b->max_chunk * rows, 1)));
     if (n_queries) {
         hipError_t e = b->d_planes.alloc(ws / 4 + 64);
         if (e != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, std::string("score-plane workspace: ") + hipGetErrorString(e));
@@ -380,7 +381,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     const uint64_t worst = ((uint64_t)fg.n + b->max_len + 2) * std::max<uint32_t>(costs->mismatch, (uint32_t)costs->gap_open + costs->gap_extend);
     bool narrow = worst <= 65534;
     if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
+    // compact layout (u16 only): 4-bit codes instead of the I plane, D rows only where they are read back.
+    // POA_CFG_FULL_PLANES (or POA_COMPACT=0) keeps all three planes, e.g. for poa_batch_fetch_planes.
+    bool compact = narrow && !(cfg && (cfg->flags & POA_CFG_FULL_PLANES));
+    if (const char* cv = getenv("POA_COMPACT")) { if (atoi(cv) == 0) compact = false; }
     b->narrow = narrow;
+    b->compact = compact;
     uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round)
     if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
     bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
@@ -408,8 +414,8 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         const uint32_t blocks = (ch.count + 3) / 4;
 #define LAUNCH_FWD(QQ, TT)                                                                                              \
     do {                                                                                                               \
-        if (fuse_tb) hipLaunchKernelGGL((poa_forward_kernel<QQ, TT, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);  \
-        else hipLaunchKernelGGL((poa_forward_kernel<QQ, TT, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);         \
+        if (fuse_tb) hipLaunchKernelGGL((poa_forward_kernel<QQ, TT, true, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);  \
+        else hipLaunchKernelGGL((poa_forward_kernel<QQ, TT, false, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);         \
     } while (0)
         uint32_t max_pitch = 0;
         for (uint32_t i = ch.first; i < ch.first + ch.count; ++i) max_pitch = std::max(max_pitch, b->h_pitch[i]);
@@ -417,7 +423,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         if (narrow) {
             uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
             if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
-            if (quads == 1) LAUNCH_FWD(1, uint16_t);
+            if (compact) {
+                if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                else hipLaunchKernelGGL((poa_forward_kernel<2, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+            } else if (quads == 1) LAUNCH_FWD(1, uint16_t);
             else LAUNCH_FWD(2, uint16_t);
         } else {
             uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);  // 256 columns per quad (4 x u32 per lane)
@@ -429,9 +438,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
-        if (!fuse_tb) {
-            if (narrow) hipLaunchKernelGGL(poa_traceback_kernel<uint16_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
-            else hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+        if (!fuse_tb || compact) {
+            if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            else hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(events[ev++], stream));
@@ -467,9 +477,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + lanes - 1) / lanes), dim3(64), 0, stream, ep);
             HIP_TRY(hipGetLastError());
             tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p;
-            hipLaunchKernelGGL(poa_traceback_kernel<uint32_t>, dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             HIP_TRY(hipGetLastError());
-            b->narrow = false;  // the planes now hold the replayed u32 table
+            b->narrow = false; b->compact = false;  // the planes now hold the replayed u32 table
         }
         HIP_TRY(hipEventRecord(events[ev++], stream));
     }
@@ -560,6 +570,7 @@ int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** 
 int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t* i, uint32_t* d) {
     if (!b || !m || !i || !d) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: null argument");
     if (!b->ran || query >= b->n_queries) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: bad query / not run");
+    if (b->compact) return fail(POA_ERR_UNSUPPORTED, "poa_batch_fetch_planes: the last run used the compact layout; run with POA_CFG_FULL_PLANES");
     const auto& last = b->chunks.back();
     if (query < last.first || query >= last.first + last.count)
         return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: the query's planes were overwritten by a later chunk");

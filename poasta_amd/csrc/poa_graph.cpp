@@ -131,6 +131,14 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
         if (has_end_child || multi) m.flags |= ROW_OPENI_ALWAYS;
         else if (!has_real) m.flags |= ROW_OPENI_NEVER;
     }
+    // D rows that must stay in memory for the compact plane layout: a row whose D some successor reads back
+    // (forward pass: non-adjacent predecessor; traceback: any predecessor of a non-chain row), plus the end row.
+    for (uint32_t r = 0; r < n; ++r) {
+        const RowMeta& m = g.rows[r];
+        if (m.flags & ROW_END) g.rows[r].flags |= ROW_STORE_D;
+        if (m.flags & ROW_CHAIN) continue;
+        for (uint32_t pe = 0; pe < m.pred_count; ++pe) g.rows[g.pred_rows[m.pred_begin + pe]].flags |= ROW_STORE_D;
+    }
     return POA_OK;
 }
 

@@ -17,6 +17,7 @@ enum : uint8_t {
                            // (insertion-open rule, src/aligner/scoring/gap_affine.rs:360-366,:413-421)
     ROW_OPENI_NEVER = 8,   // no successors at all (only the end row)
     ROW_CHAIN = 16,        // exactly one predecessor and it is the previous row
+    ROW_STORE_D = 32,      // some successor reads this row's D from memory (it is not a chain row right below): keep the D row
 };
 
 struct RowMeta {  // 16 bytes, one per row

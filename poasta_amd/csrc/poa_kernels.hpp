@@ -147,6 +147,7 @@ struct TbCtx {
     const T* M;
     const T* I;
     const T* D;
+    const uint32_t* codes;  // compact layout: nibble per cell at the I plane's place
     const uint8_t* q;
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
@@ -155,6 +156,7 @@ struct TbCtx {
 struct TbStep {
     uint32_t row, j, st;  // st: 0 M, 1 D, 2 I
     bool found;
+    uint32_t cs;          // score of the cell the step started from
 };
 
 template <typename T>
@@ -171,23 +173,31 @@ __device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j
 }
 
 template <typename T>
-__device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st, uint32_t& n_cand,
+__device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    return (c.codes[(uint64_t)row * (c.pitch / 8) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
+}
+// gap_cs: the score of the current D / I cell, carried along the walk (compact layout has no I plane and
+// only some D rows; with full planes it equals the stored value and the stored value is used).
+template <typename T, bool COMPACT>
+__device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st, uint32_t gap_cs, uint32_t& n_cand,
                                  bool& bad, bool& panic) {
-    TbStep first{0, 0, 0, false};
+    TbStep first{0, 0, 0, false, 0};
     n_cand = 0;
     const RowMeta m = c.rows[row];
     const bool is_end = (m.flags & ROW_END) != 0;
     auto sub = [&](uint32_t a, uint32_t b) { uint32_t r = a - b; if (r == INF) panic = true; return r; };
     auto cand = [&](uint32_t r2, uint32_t j2, uint32_t s2) {
-        if (!first.found) first = TbStep{r2, j2, s2, true};
+        if (!first.found) { first.row = r2; first.j = j2; first.st = s2; first.found = true; }
         n_cand++;
     };
     if (st == 0) {
         // all loads of the step are issued before the first use (one memory round-trip for chain rows)
         const uint32_t cs = pl(c.M, c.pitch, row, j);
-        const uint32_t dv = pl(c.D, c.pitch, row, j);
-        const uint32_t iv = pl(c.I, c.pitch, row, j);
+        uint32_t dv = 0, iv = 0, code = 0;
+        if (COMPACT) code = tb_code(c, row, j);
+        else { dv = pl(c.D, c.pitch, row, j); iv = pl(c.I, c.pitch, row, j); }
         const uint32_t up = (row > 0 && j > 0) ? pl(c.M, c.pitch, row - 1, j - 1) : INF;  // the usual diagonal predecessor
+        first.cs = cs;
         if (cs == INF) return first;
         if (j > 0) {
             const bool moe = is_end || ((uint32_t)m.sym == (uint32_t)c.q[j - 1]);
@@ -202,10 +212,11 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
                 }
             }
         }
-        if (dv == cs) cand(row, j, 1);
-        if (iv == cs) cand(row, j, 2);
+        if (COMPACT ? (code & 4u) != 0 : dv == cs) cand(row, j, 1);
+        if (COMPACT ? (code & 1u) != 0 : iv == cs) cand(row, j, 2);
     } else if (st == 1) {
-        const uint32_t cs = pl(c.D, c.pitch, row, j);
+        const uint32_t cs = COMPACT ? gap_cs : pl(c.D, c.pitch, row, j);
+        first.cs = cs;
         if (cs == INF) return first;
         if (m.pred_count == 0) return first;
         const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
@@ -216,23 +227,29 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
             if (ps == t_open) cand(pr, j, 0);
             else if (!real_open && ps < t_open) bad = true;  // phantom edge the reference does not re-check
         }
-        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-            const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-            if (pl(c.D, c.pitch, pr, j) == t_ext) cand(pr, j, 1);
+        if (COMPACT && (m.flags & ROW_CHAIN)) {
+            // single predecessor right above: D[row][j] == D[row-1][j] + e is code bit 3
+            if (tb_code(c, row, j) & 8u) cand(row - 1, j, 1);
+        } else {
+            for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+                const uint32_t pr = c.pred_rows[m.pred_begin + pe];
+                if (pl(c.D, c.pitch, pr, j) == t_ext) cand(pr, j, 1);  // predecessors of a non-chain row keep their D row
+            }
         }
     } else {
-        const uint32_t cs = pl(c.I, c.pitch, row, j);
+        const uint32_t cs = COMPACT ? gap_cs : pl(c.I, c.pitch, row, j);
+        first.cs = cs;
         if (cs == INF) return first;
         if (j > 0) {
             const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
             const uint32_t pm = pl(c.M, c.pitch, row, j - 1);
-            const uint32_t pi = pl(c.I, c.pitch, row, j - 1);
             if (pm == t_open) cand(row, j - 1, 0);
             else if (!tb_open_i(c, m, j - 1) && pm < t_open) bad = true;
-            if (pi == t_ext) {
+            const bool ext = COMPACT ? (tb_code(c, row, j) & 2u) != 0 : pl(c.I, c.pitch, row, j - 1) == t_ext;
+            if (ext) {
                 const bool only = (n_cand == 0);
                 cand(row, j - 1, 0);  // sic: the reference returns Match here (gap_affine.rs:649)
-                if (only && pm != pi) bad = true;  // the hop lands on M[row][j-1] which is not this I value
+                if (only && pm != t_ext) bad = true;  // the hop lands on M[row][j-1] which is not that I value
             }
         }
     }
@@ -245,7 +262,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
 // lanes whose step really is that diagonal move is accepted at once.  The first lane that deviates
 // (gap open/close, bubble predecessor, start reached) is then handled exactly like the sequential
 // rule, so the emitted alignment and flags are identical to a step-by-step walk.
-template <typename T>
+template <typename T, bool COMPACT>
 __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t qi, const uint32_t lane) {
     if (P.exact_pass) {
         const uint32_t stt = P.ex_status[qi];
@@ -265,6 +282,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     c.M = reinterpret_cast<const T*>(P.planes) + P.plane_off[qi];
     c.I = c.M + RP;
     c.D = c.I + RP;
+    c.codes = reinterpret_cast<const uint32_t*>(c.I);
     c.start_row = P.start_row; c.end_row = P.end_row;
     c.x = P.cost_x; c.o = P.cost_o; c.e = P.cost_e;
     const uint32_t L = c.L;
@@ -283,6 +301,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
 
     bool done = false;
     uint32_t crow = 0, cj = 0, cst = 0;
+    uint32_t gcs = INF;  // score of the current D / I cell (wave-uniform)
     if (L == 0) done = true;
     if (!done && L == 1) {
         // gap_affine.rs:812-824: the end node equals every symbol -> always [(end, 0)]
@@ -293,17 +312,20 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     }
     if (!done) {
         // first hop from the end cell: Match, .or_else(Insertion), .or_else(Deletion) (gap_affine.rs:832-835)
-        uint32_t f0 = 0, fr = 0, fj = 0, fs = 0, fallback = 0;
+        uint32_t f0 = 0, fr = 0, fj = 0, fs = 0, fallback = 0, fg = INF;
         if (lane == 0) {
             uint32_t nc; bool bad = false, pn = false;
-            TbStep cur = tb_step(c, c.end_row, L, 0, nc, bad, pn);
+            TbStep cur = tb_step<T, COMPACT>(c, c.end_row, L, 0, INF, nc, bad, pn);
+            fg = cur.cs;
             if (pn) f0 |= POA_FLAG_REF_PANIC;
             if (cur.found && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
             if (!cur.found) {
-                cur = tb_step(c, c.end_row, L, 2, nc, bad, pn);
-                if (!cur.found) cur = tb_step(c, c.end_row, L, 1, nc, bad, pn);
+                // the end row has no insertion state (I[end] = INF) and keeps its D row in every layout
+                cur = tb_step<T, COMPACT>(c, c.end_row, L, 2, INF, nc, bad, pn);
+                if (!cur.found) { cur = tb_step<T, COMPACT>(c, c.end_row, L, 1, pl(c.D, c.pitch, c.end_row, L), nc, bad, pn); fg = cur.cs; }
                 if (!cur.found) { f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
                 else f0 |= POA_FLAG_AMBIGUOUS;
+                if (cur.found && cur.st == 1) fg = cur.cs - c.e;  // stepped D -> D
             }
             fr = cur.row; fj = cur.j; fs = cur.st;
         }
@@ -315,7 +337,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
             }
             done = true;
         } else {
-            crow = bc(fr, 0); cj = bc(fj, 0); cst = bc(fs, 0);
+            crow = bc(fr, 0); cj = bc(fj, 0); cst = bc(fs, 0); gcs = bc(fg, 0);
         }
     }
     bool reached_start = done;  // nothing to truncate in the special cases
@@ -328,10 +350,10 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         }
         const bool active = lane < depth;
         const uint32_t my_row = crow - lane, my_j = cj - lane;
-        TbStep bt{0, 0, 0, false};
+        TbStep bt{0, 0, 0, false, 0};
         uint32_t nc = 0;
         bool bad = false, pn = false;
-        if (active) bt = tb_step(c, my_row, my_j, cst, nc, bad, pn);
+        if (active) bt = tb_step<T, COMPACT>(c, my_row, my_j, cst, gcs, nc, bad, pn);
         const bool amb = active && bt.found && (nc != 1 || bad);
         const bool quirk = active && bt.found && bt.st == 0 && bt.j == 0 && bt.row != c.start_row && cst != 1 &&
                            (uint32_t)c.rows[bt.row].sym == (uint32_t)c.q[0];
@@ -354,12 +376,14 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         // lane p deviates: replay the sequential rule with its results
         const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
         const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_pn = bc(pn ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
+        const uint32_t d_cs = bc(bt.cs, p);
         const uint32_t cur_row = crow - p, cur_j = cj - p, cur_st = (p == 0) ? cst : 0u;
         if (d_pn) flags |= POA_FLAG_REF_PANIC;
         if (!d_found) break;
         if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
         if (cur_st == 0 && d_st != 0) {  // zero-cost gap close: no pair (gap_affine.rs:871-875)
             crow = d_row; cj = d_j; cst = d_st;
+            gcs = d_cs;  // the gap cell has the Match cell's score
             continue;
         }
         if (lane == 0) {
@@ -371,6 +395,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         cnt += 1;
         if (d_quirk) flags |= POA_FLAG_START_QUIRK;
         if (d_row == c.start_row) { reached_start = true; break; }
+        if (cur_st == 1 && d_st == 1) gcs = d_cs - c.e;  // D -> D: one more extension
         crow = d_row; cj = d_j; cst = d_st;
     }
     if (!reached_start) flags |= POA_FLAG_TRUNCATED;
@@ -381,12 +406,12 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     }
 }
 
-template <typename T>
+template <typename T, bool COMPACT>
 __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
-    traceback_wave<T>(P, P.first_query + wq, lane);
+    traceback_wave<T, COMPACT>(P, P.first_query + wq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,8 +424,13 @@ __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
 // neighbour is an in-register value except for k = 0 (one DPP wave_shr:1 per quad).
 // FUSE_TB: the wave traces its own query right after its last row (the latency-bound traceback then overlaps
 // other waves' HBM-bound forward work instead of running as a separate launch).
-template <int Q, typename T, bool FUSE_TB>
+// COMPACT (u16 planes only): the I plane is replaced by a 4-bit code per cell and D rows are written only where a
+// later row reads them back (ROW_STORE_D).  Codes, one nibble per cell, 8 cells per dword, row-major at the I plane's
+// place:  bit0 I==M   bit1 I[j]==I[j-1]+e   bit2 D==M   bit3 D==PD+e.  They are exactly the predicates the
+// traceback evaluates on I and (for chain rows) D; see traceback_wave.
+template <int Q, typename T, bool FUSE_TB, bool COMPACT>
 __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams TP) {
+    static_assert(!COMPACT || PlaneIO<T>::K == 8, "compact codes assume 8 columns per lane and quad");
     using IO = PlaneIO<T>;
     constexpr int K = IO::K;
     constexpr int C = K * Q;
@@ -418,7 +448,7 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams 
     T* __restrict__ Mp = reinterpret_cast<T*>(P.planes) + P.plane_off[qi];
     T* __restrict__ Ip = Mp + RP;
     T* __restrict__ Dp = Ip + RP;
-    uint32_t* __restrict__ carry = P.strip_carry + (uint64_t)wq * P.n_rows;
+    uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;  // [2r]: I entering the next strip, [2r+1]: I of my last column
     const uint32_t x = P.cost_x, oe = P.cost_oe, e = P.cost_e;
     const uint32_t n_strips = (pitch + W - 1) / W;
     const uint32_t step = K * e;                      // one lane == K columns
@@ -545,7 +575,7 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams 
                     Tq[m] = t;  // leaves my last column of quad m (carry-in INF)
                 }
                 // cross-lane: independent scans per quad, then a uniform carry chain over the quads
-                uint32_t cq = (s > 0) ? carry[r] : INF;  // insertion value entering column sbase
+                uint32_t cq = (s > 0) ? carry[2 * r] : INF;  // insertion value entering column sbase
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
                     const uint32_t Pm = wave_scan_min_plus(Tq[m], step, w15, w31);
@@ -557,18 +587,48 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams 
 #pragma unroll
                     for (int k = 1; k < K; ++k) Ic[K * m + k] = umin(Ic[K * m + k], sat_add(cin, (uint32_t)k * e));
                 }
-                if (n_strips > 1 && lane == 0) carry[r] = cq;  // I[r][(s+1)*W]
+                if (n_strips > 1 && lane == 0) carry[2 * r] = cq;  // I[r][(s+1)*W]
 #pragma unroll
                 for (int k = 0; k < C; ++k) Mc[k] = umin(H[k], Ic[k]);
             }
 
+            if (!COMPACT) {
 #pragma unroll
-            for (int m = 0; m < Q; ++m) {
-                if (act[m]) {
-                    IO::store(Mp + rbase + m * QW, &Mc[K * m]);
-                    IO::store(Ip + rbase + m * QW, &Ic[K * m]);
-                    IO::store(Dp + rbase + m * QW, &Dc[K * m]);
+                for (int m = 0; m < Q; ++m) {
+                    if (act[m]) {
+                        IO::store(Mp + rbase + m * QW, &Mc[K * m]);
+                        IO::store(Ip + rbase + m * QW, &Ic[K * m]);
+                        IO::store(Dp + rbase + m * QW, &Dc[K * m]);
+                    }
                 }
+            } else {
+                uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
+                const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+                uint32_t edge_i = INF;  // I of the column left of my first column of the quad
+                if (s > 0) edge_i = carry[2 * r + 1];
+                // (for s > 0 the value was written by lane 63 at the end of the previous strip of this row)
+#pragma unroll
+                for (int m = 0; m < Q; ++m) {
+                    const uint32_t i_left = wave_shr1(Ic[K * m + K - 1], edge_i);
+                    edge_i = (uint32_t)__builtin_amdgcn_readlane((int)Ic[K * m + K - 1], 63);
+                    uint32_t code = 0;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const int i = K * m + k;
+                        const uint32_t ip = (k == 0) ? i_left : Ic[i - 1];
+                        uint32_t nb = (Ic[i] == Mc[i]) ? 1u : 0u;
+                        nb |= (Ic[i] == sat_add(ip, e)) ? 2u : 0u;
+                        nb |= (Dc[i] == Mc[i]) ? 4u : 0u;
+                        nb |= (Dc[i] == sat_add(PD[i], e)) ? 8u : 0u;
+                        code |= nb << (4 * k);
+                    }
+                    if (act[m]) {
+                        IO::store(Mp + rbase + m * QW, &Mc[K * m]);
+                        if (keep_d) IO::store(Dp + rbase + m * QW, &Dc[K * m]);
+                        codes[m * (QW / 8)] = code;
+                    }
+                }
+                if (n_strips > 1 && lane == 63) carry[2 * r + 1] = Ic[C - 1];  // I[r][(s+1)*W - 1]
             }
 #pragma unroll
             for (int k = 0; k < C; ++k) { Mprev[k] = Mc[k]; Dprev[k] = Dc[k]; }
@@ -577,7 +637,7 @@ __global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams 
     }
     if (FUSE_TB) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // my plane stores are complete before I read them back
-        traceback_wave<T>(TP, qi, lane);
+        traceback_wave<T, COMPACT>(TP, qi, lane);
     }
 }
 

@@ -28,7 +28,7 @@ def _check_against_dense(engine, oracle, g, qs, costs=(4, 6, 2), planes=False):
     al = engine.PoastaAligner(engine.AffineMinGapCost(_costs(engine, *costs)))
     if planes:
         rb = engine.ResidentBatch(g, qseq, qoff)
-        rb.run(_costs(engine, *costs))
+        rb.run(_costs(engine, *costs), None, engine.make_config(full_planes=True))  # all three planes kept for the comparison
         res = rb.fetch()
         node_rows = rb.dg.node_rows()
         orank = og.export_csr()["rank"]
