@@ -17,6 +17,7 @@
 #include "poa_graph.hpp"
 #include "poa_exact_kernel.hpp"
 #include "poa_kernels.hpp"
+#include "poa_forward_packed.hpp"
 
 using namespace poa_amd;
 
@@ -385,6 +386,8 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     // POA_CFG_FULL_PLANES (or POA_COMPACT=0) keeps all three planes, e.g. for poa_batch_fetch_planes.
     bool compact = narrow && !(cfg && (cfg->flags & POA_CFG_FULL_PLANES));
     if (const char* cv = getenv("POA_COMPACT")) { if (atoi(cv) == 0) compact = false; }
+    bool packed = true;  // packed-u16 arithmetic kernel for the compact layout (POA_PACKED=0: scalar u32 arithmetic)
+    if (const char* pv2 = getenv("POA_PACKED")) packed = atoi(pv2) != 0;
     b->narrow = narrow;
     b->compact = compact;
     uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round)
@@ -423,7 +426,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         if (narrow) {
             uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
             if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
-            if (compact) {
+            if (compact && packed) {
+                if (quads == 1) hipLaunchKernelGGL((poa_forward_packed_kernel<1>), dim3(blocks), dim3(256), 0, stream, fp);
+                else hipLaunchKernelGGL((poa_forward_packed_kernel<2>), dim3(blocks), dim3(256), 0, stream, fp);
+            } else if (compact) {
                 if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
                 else hipLaunchKernelGGL((poa_forward_kernel<2, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
             } else if (quads == 1) LAUNCH_FWD(1, uint16_t);

@@ -1,0 +1,266 @@
+// Packed-u16 forward kernel (gfx950): the same recurrences and the same compact plane layout as
+// poa_forward_kernel<Q, uint16_t, *, true> (poa_kernels.hpp), but two columns per VGPR and
+// per VALU instruction: v_pk_add_u16 clamp / v_pk_min_u16 / v_pk_max_u16 / v_pk_sub_u16.
+// INF is 0xFFFF per half and the clamp saturates there, so INF stays absorbing; the launcher only
+// selects this kernel when every finite score provably fits 16 bits (see poa_batch_run_ex).
+//
+// The packed primitives are inline asm on purpose: written as vector C, LLVM canonicalises the
+// branch-free forms (e.g. 0 - umin(x,1)) back into per-half compares + v_cndmask + v_perm, five
+// instructions instead of two.  asm VALU producers are invisible to the hazard recognizer, so every
+// DPP that may read an asm-written VGPR is itself asm with the two wait states the ISA asks for.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "poa_kernels.hpp"
+
+namespace poa_amd {
+
+#define POA_PK2(NAME, INSN)                                                                       \
+    __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) {                            \
+        uint32_t r;                                                                               \
+        asm(INSN : "=v"(r) : "v"(a), "v"(b));                                                     \
+        return r;                                                                                 \
+    }
+POA_PK2(pk_min, "v_pk_min_u16 %0, %1, %2")
+POA_PK2(pk_max, "v_pk_max_u16 %0, %1, %2")
+POA_PK2(pk_sub, "v_pk_sub_u16 %0, %1, %2")
+POA_PK2(pk_add_sat, "v_pk_add_u16 %0, %1, %2 clamp")
+POA_PK2(pk_sub_sat, "v_pk_sub_u16 %0, %1, %2 clamp")
+#undef POA_PK2
+
+// lane l <- x of lane l-1, lane 0 <- fill; safe behind an asm VALU write of x (2 wait states)
+__device__ __forceinline__ uint32_t pk_wave_shr1(uint32_t x, uint32_t fill) {
+    uint32_t r = fill;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(x));
+    return r;
+}
+// (hi << 16) | (lo >> 16): the packed register shifted right by one column, `lo` supplying the new low half
+__device__ __forceinline__ uint32_t shr_col(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return umin(umin(a, b), c); }
+
+// inclusive min-plus scan over the lanes, values clamped to the 16-bit INF
+__device__ __forceinline__ uint32_t wave_scan_min_plus16(uint32_t t, uint32_t step, uint32_t w15, uint32_t w31) {
+    constexpr uint32_t I16 = 0xFFFFu;
+    uint32_t P = t;
+    P = umin3(P, (uint32_t)__builtin_amdgcn_update_dpp((int)I16, (int)P, 0x111, 0xF, 0xF, false) + step, I16);
+    P = umin3(P, (uint32_t)__builtin_amdgcn_update_dpp((int)I16, (int)P, 0x112, 0xF, 0xF, false) + 2 * step, I16);
+    P = umin3(P, (uint32_t)__builtin_amdgcn_update_dpp((int)I16, (int)P, 0x114, 0xF, 0xF, false) + 4 * step, I16);
+    P = umin3(P, (uint32_t)__builtin_amdgcn_update_dpp((int)I16, (int)P, 0x118, 0xF, 0xF, false) + 8 * step, I16);
+    P = umin3(P, (uint32_t)__builtin_amdgcn_update_dpp((int)I16, (int)P, 0x142, 0xA, 0xF, false) + w15, I16);
+    P = umin3(P, (uint32_t)__builtin_amdgcn_update_dpp((int)I16, (int)P, 0x143, 0xC, 0xF, false) + w31, I16);
+    return P;
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
+    constexpr int K = 8;                 // columns per lane and quad
+    constexpr int NP = 4 * Q;            // packed registers per row array (2 columns each)
+    constexpr uint32_t QW = 64 * K;      // 512 columns per quad
+    constexpr uint32_t W = QW * Q;
+    constexpr uint32_t I16 = 0xFFFFu, INF2 = 0xFFFFFFFFu, ONE2 = 0x00010001u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    if (wq >= P.n_queries) return;
+    const uint32_t qi = P.first_query + wq;
+    const uint64_t qbeg = P.qoff[qi];
+    const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
+    const uint8_t* __restrict__ q = P.qseq + qbeg;
+    const uint32_t pitch = P.pitch[qi];
+    const uint64_t RP = (uint64_t)P.n_rows * pitch;
+    uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
+    uint16_t* __restrict__ Ip = Mp + RP;  // holds the 4-bit codes
+    uint16_t* __restrict__ Dp = Ip + RP;
+    uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;
+    const uint32_t e = P.cost_e, oe = P.cost_oe, x = P.cost_x;
+    const uint32_t e2 = e | (e << 16), oe2 = oe | (oe << 16), x2 = x | (x << 16);
+    const uint32_t n_strips = (pitch + W - 1) / W;
+    const uint32_t step = K * e;
+    const uint32_t w15 = ((lane & 15u) + 1u) * step;
+    const uint32_t w31 = (lane - 31u) * step;
+    const uint32_t lane_off = K * lane * e;
+    uint32_t off2[4];  // cost of extending an insertion from my first column of a quad to columns 2i, 2i+1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) off2[i] = (2 * i * e) | ((2 * i + 1) * e << 16);
+    const uint32_t zero = 0, one2 = ONE2, inf2 = INF2;
+
+    for (uint32_t s = 0; s < n_strips; ++s) {
+        const uint32_t sbase = s * W;
+        bool act[Q];
+        uint32_t qP[NP];   // my query symbols, 16 bits each (0 past the end: never a symbol)
+        uint32_t qlE[Q];   // symbol left of my first column of quad m, in the HIGH half
+#pragma unroll
+        for (int m = 0; m < Q; ++m) {
+            const uint32_t c0 = sbase + m * QW + K * lane;
+            act[m] = c0 < pitch;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const uint32_t c = c0 + 2 * pp;
+                const uint32_t lo = (c < L) ? (uint32_t)q[c] : 0u, hi = (c + 1 < L) ? (uint32_t)q[c + 1] : 0u;
+                qP[4 * m + pp] = lo | (hi << 16);
+            }
+            qlE[m] = ((c0 > 0 && c0 - 1 < L) ? (uint32_t)q[c0 - 1] : 0u) << 16;
+        }
+        uint32_t Mprev[NP], Dprev[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { Mprev[p] = inf2; Dprev[p] = inf2; }
+
+        for (uint32_t r = 0; r < P.n_rows; ++r) {
+            const RowMeta meta = P.rows[r];
+            const uint32_t sym = meta.sym;
+            const uint32_t sym2 = sym | (sym << 16);
+            const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
+            uint32_t PM[NP], PD[NP], PMl[Q];  // PMl: hi half = min over predecessors of M[p][my first column - 1]
+
+            if (meta.flags & ROW_CHAIN) {
+                uint32_t edge = inf2;
+                if (s > 0) edge = (uint32_t)Mp[(uint64_t)(r - 1) * pitch + sbase - 1] << 16;
+#pragma unroll
+                for (int m = 0; m < Q; ++m) {
+                    PMl[m] = pk_wave_shr1(Mprev[4 * m + 3], edge);
+                    edge = (uint32_t)__builtin_amdgcn_readlane((int)Mprev[4 * m + 3], 63);
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { PM[p] = Mprev[p]; PD[p] = Dprev[p]; }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { PM[p] = inf2; PD[p] = inf2; }
+#pragma unroll
+                for (int m = 0; m < Q; ++m) PMl[m] = inf2;
+                if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
+                    const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
+                    const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
+                    uint32_t tm[NP], td[NP];
+                    if (pr + 1 == r) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) { tm[p] = Mprev[p]; td[p] = Dprev[p]; }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < Q; ++m) {
+                            uint4 a = make_uint4(inf2, inf2, inf2, inf2), b = a;
+                            if (act[m]) {
+                                a = *reinterpret_cast<const uint4*>(Mp + pbase + m * QW);
+                                b = *reinterpret_cast<const uint4*>(Dp + pbase + m * QW);
+                            }
+                            tm[4 * m] = a.x; tm[4 * m + 1] = a.y; tm[4 * m + 2] = a.z; tm[4 * m + 3] = a.w;
+                            td[4 * m] = b.x; td[4 * m + 1] = b.y; td[4 * m + 2] = b.z; td[4 * m + 3] = b.w;
+                        }
+                    }
+                    uint32_t edge = inf2;
+                    if (s > 0) edge = (uint32_t)Mp[(uint64_t)pr * pitch + sbase - 1] << 16;
+#pragma unroll
+                    for (int m = 0; m < Q; ++m) {
+                        PMl[m] = pk_min(PMl[m], pk_wave_shr1(tm[4 * m + 3], edge));
+                        edge = (uint32_t)__builtin_amdgcn_readlane((int)tm[4 * m + 3], 63);
+                    }
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) { PM[p] = pk_min(PM[p], tm[p]); PD[p] = pk_min(PD[p], td[p]); }
+                }
+            }
+
+            uint32_t Mc[NP], Ic[NP], Dc[NP], Hc[NP], PDe[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) PDe[p] = pk_add_sat(PD[p], e2);
+            if (meta.flags & ROW_END) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    Dc[p] = PDe[p];
+                    Mc[p] = pk_min(PM[p], Dc[p]);
+                    Ic[p] = inf2;
+                    Hc[p] = Mc[p];
+                }
+            } else {
+                // insertion-open rule, branch-free: "always" == the child symbol 0, which no query symbol equals
+                // (past the query end q is 0 too: not open there, as the rule wants).  ROW_OPENI_NEVER only
+                // occurs on the end row, handled above.
+                const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
+                const uint32_t csym2 = cs1 | (cs1 << 16);
+                const uint32_t start_keep = ((meta.flags & ROW_START) && sbase == 0 && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                uint32_t Tq[Q];
+#pragma unroll
+                for (int m = 0; m < Q; ++m) {
+                    uint32_t mm_prev = ((qlE[m] >> 16) != sym) ? 0xFFFF0000u : 0u;  // mismatch of the column left of the quad (hi half)
+                    uint32_t pm_prev = PMl[m];
+                    uint32_t t = I16;  // in-lane insertion chain (32-bit scalar in the 16-bit domain)
+                    uint32_t iloc[4];
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const int p = 4 * m + pp;
+                        // 0xFFFF where the query symbol differs from the row's symbol
+                        const uint32_t mm = pk_sub(zero, pk_min(qP[p] ^ sym2, one2));
+                        Dc[p] = pk_min(PDe[p], pk_max(pk_add_sat(PM[p], oe2), ~mm));
+                        const uint32_t pm_s = shr_col(PM[p], pm_prev);  // M of the predecessor(s), one column to the left
+                        const uint32_t mm_s = shr_col(mm, mm_prev);
+                        Hc[p] = pk_min(pk_add_sat(pm_s, mm_s & x2), Dc[p]);
+                        pm_prev = PM[p]; mm_prev = mm;
+                        if (m == 0 && pp == 0) Hc[p] &= start_keep;  // H[start][0] = 0
+                        // insertion open: A = (q != child symbol) ? H + oe : INF
+                        const uint32_t a = pk_max(pk_add_sat(Hc[p], oe2), ~pk_sub(zero, pk_min(qP[p] ^ csym2, one2)));
+                        const uint32_t a_lo = a & 0xFFFFu, a_hi = a >> 16;
+                        const uint32_t i_lo = t;
+                        t = umin3(t + e, a_lo, I16);
+                        iloc[pp] = i_lo | (t << 16);
+                        t = umin3(t + e, a_hi, I16);
+                    }
+                    Tq[m] = t;
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = iloc[pp];
+                }
+                uint32_t cq = (s > 0) ? carry[2 * r] : I16;
+#pragma unroll
+                for (int m = 0; m < Q; ++m) {
+                    const uint32_t Pm = wave_scan_min_plus16(Tq[m], step, w15, w31);
+                    const uint32_t excl = wave_shr1(Pm, I16);
+                    const uint32_t cin = umin3(excl, cq + lane_off, I16);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
+                    cq = umin3(cq + QW * e, total, I16);
+                    const uint32_t cin2 = cin | (cin << 16);
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = pk_min(Ic[4 * m + pp], pk_add_sat(cin2, off2[pp]));
+                }
+                if (n_strips > 1 && lane == 0) carry[2 * r] = cq;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) Mc[p] = pk_min(Hc[p], Ic[p]);
+            }
+
+            // 4-bit codes (bit set == predicate holds): I==M, I[j]==I[j-1]+e, D==M, D==PD+e; 8 cells per dword
+            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
+            const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+            uint32_t edge_i = inf2;
+            if (s > 0) edge_i = carry[2 * r + 1] << 16;
+#pragma unroll
+            for (int m = 0; m < Q; ++m) {
+                uint32_t i_prev = pk_wave_shr1(Ic[4 * m + 3], edge_i);
+                edge_i = (uint32_t)__builtin_amdgcn_readlane((int)Ic[4 * m + 3], 63);
+                uint32_t word = 0;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int p = 4 * m + pp;
+                    const uint32_t i_left = shr_col(Ic[p], i_prev);
+                    i_prev = Ic[p];
+                    // "not equal" flags (0/1 per half); every pair below satisfies lhs >= rhs, so lhs -sat rhs == 0 <=> equal
+                    const uint32_t neA = pk_min(pk_sub_sat(Ic[p], Hc[p]), one2);                        // I == M  <=>  I <= H
+                    const uint32_t neB = pk_min(pk_sub_sat(pk_add_sat(i_left, e2), Ic[p]), one2);       // I[j] == I[j-1] + e
+                    const uint32_t neC = pk_min(pk_sub_sat(Dc[p], Mc[p]), one2);                        // D == M
+                    const uint32_t neD = pk_min(pk_sub_sat(PDe[p], Dc[p]), one2);                       // D == PD + e
+                    const uint32_t c = neA | (neB << 1) | (neC << 2) | (neD << 3);
+                    word |= ((c | (c >> 12)) & 0xFFu) << (8 * pp);
+                }
+                if (act[m]) {
+                    *reinterpret_cast<uint4*>(Mp + rbase + m * QW) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
+                    if (keep_d)
+                        *reinterpret_cast<uint4*>(Dp + rbase + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
+                    codes[m * (QW / 8)] = ~word;
+                }
+            }
+            if (n_strips > 1 && lane == 63) carry[2 * r + 1] = Ic[NP - 1] >> 16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { Mprev[p] = Mc[p]; Dprev[p] = Dc[p]; }
+        }
+        if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
+}  // namespace poa_amd

@@ -29,6 +29,10 @@
 #include "../../include/poasta_amd.h"
 #include "poa_graph.hpp"
 
+#ifndef POA_FWD_MIN_WAVES
+#define POA_FWD_MIN_WAVES 1
+#endif
+
 namespace poa_amd {
 
 constexpr uint32_t INF = 0xFFFFFFFFu;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
 // place:  bit0 I==M   bit1 I[j]==I[j-1]+e   bit2 D==M   bit3 D==PD+e.  They are exactly the predicates the
 // traceback evaluates on I and (for chain rows) D; see traceback_wave.
 template <int Q, typename T, bool FUSE_TB, bool COMPACT>
-__global__ __launch_bounds__(256) void poa_forward_kernel(FwdParams P, TbParams TP) {
+__global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(FwdParams P, TbParams TP) {
     static_assert(!COMPACT || PlaneIO<T>::K == 8, "compact codes assume 8 columns per lane and quad");
     using IO = PlaneIO<T>;
     constexpr int K = IO::K;
