@@ -4,10 +4,10 @@
 // INF is 0xFFFF per half and the clamp saturates there, so INF stays absorbing; the launcher only
 // selects this kernel when every finite score provably fits 16 bits (see poa_batch_run_ex).
 //
-// The packed primitives are inline asm on purpose: written as vector C, LLVM canonicalises the
-// branch-free forms (e.g. 0 - umin(x,1)) back into per-half compares + v_cndmask + v_perm, five
-// instructions instead of two.  asm VALU producers are invisible to the hazard recognizer, so every
-// DPP that may read an asm-written VGPR is itself asm with the two wait states the ISA asks for.
+// Everything is written with clang's elementwise vector builtins on a 2 x u16 vector; the 0/1 flags use
+// forms LLVM leaves alone (1 -sat d), because the obvious ones (umin(d, 1), compares, 0 - flag) are
+// canonicalised into per-half v_cmp + v_cndmask + v_perm.  (An inline-asm version of the same primitives
+// measured no faster: the compiler pads every asm statement with s_nop and cannot schedule across them.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,25 +16,27 @@
 
 namespace poa_amd {
 
-#define POA_PK2(NAME, INSN)                                                                       \
-    __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) {                            \
-        uint32_t r;                                                                               \
-        asm(INSN : "=v"(r) : "v"(a), "v"(b));                                                     \
-        return r;                                                                                 \
-    }
-POA_PK2(pk_min, "v_pk_min_u16 %0, %1, %2")
-POA_PK2(pk_max, "v_pk_max_u16 %0, %1, %2")
-POA_PK2(pk_sub, "v_pk_sub_u16 %0, %1, %2")
-POA_PK2(pk_add_sat, "v_pk_add_u16 %0, %1, %2 clamp")
-POA_PK2(pk_sub_sat, "v_pk_sub_u16 %0, %1, %2 clamp")
-#undef POA_PK2
+typedef unsigned short poa_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ poa_u16x2 pkv(uint32_t a) { return __builtin_bit_cast(poa_u16x2, a); }
+__device__ __forceinline__ uint32_t pku(poa_u16x2 a) { return __builtin_bit_cast(uint32_t, a); }
+// v_pk_add_u16 clamp / v_pk_sub_u16 clamp / v_pk_min_u16 / v_pk_max_u16 / v_pk_lshlrev_b16
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) { return pku(__builtin_elementwise_add_sat(pkv(a), pkv(b))); }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return pku(__builtin_elementwise_sub_sat(pkv(a), pkv(b))); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return pku(__builtin_elementwise_min(pkv(a), pkv(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pku(__builtin_elementwise_max(pkv(a), pkv(b))); }
+template <int S>
+__device__ __forceinline__ uint32_t pk_shl(uint32_t a) { return pku(pkv(a) << (unsigned short)S); }
+// 1 per half where the halves of a and b are equal, GIVEN a >= b per half (saturating difference is 0 iff equal).
+// Written as 1 -sat (a -sat b): LLVM keeps both as v_pk_sub_u16 ... clamp (an explicit umin(d, 1) or a compare
+// is canonicalised into per-half v_cmp + v_cndmask + v_perm, five instructions).
+__device__ __forceinline__ uint32_t pk_eq_ge(uint32_t a, uint32_t b) { return pk_sub_sat(0x00010001u, pk_sub_sat(a, b)); }
+// 1 per half where the half of z is zero
+__device__ __forceinline__ uint32_t pk_is_zero(uint32_t z) { return pk_sub_sat(0x00010001u, z); }
+// v where sel1 (0/1 per half) is 0, INF (0xFFFF) where it is 1:  max(v, 0 - sel1)   (v_pk_sub_i16 + v_pk_max_u16)
+__device__ __forceinline__ uint32_t pk_inf_where(uint32_t v, uint32_t sel1) { return pk_max(v, pku(pkv(0u) - pkv(sel1))); }
 
-// lane l <- x of lane l-1, lane 0 <- fill; safe behind an asm VALU write of x (2 wait states)
-__device__ __forceinline__ uint32_t pk_wave_shr1(uint32_t x, uint32_t fill) {
-    uint32_t r = fill;
-    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(x));
-    return r;
-}
+// lane l <- x of lane l-1, lane 0 <- fill
+__device__ __forceinline__ uint32_t pk_wave_shr1(uint32_t x, uint32_t fill) { return wave_shr1(x, fill); }
 // (hi << 16) | (lo >> 16): the packed register shifted right by one column, `lo` supplying the new low half
 __device__ __forceinline__ uint32_t shr_col(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
     constexpr int NP = 4 * Q;            // packed registers per row array (2 columns each)
     constexpr uint32_t QW = 64 * K;      // 512 columns per quad
     constexpr uint32_t W = QW * Q;
-    constexpr uint32_t I16 = 0xFFFFu, INF2 = 0xFFFFFFFFu, ONE2 = 0x00010001u;
+    constexpr uint32_t I16 = 0xFFFFu, INF2 = 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
     uint32_t off2[4];  // cost of extending an insertion from my first column of a quad to columns 2i, 2i+1
 #pragma unroll
     for (int i = 0; i < 4; ++i) off2[i] = (2 * i * e) | ((2 * i + 1) * e << 16);
-    const uint32_t zero = 0, one2 = ONE2, inf2 = INF2;
+    const uint32_t inf2 = INF2;
 
     for (uint32_t s = 0; s < n_strips; ++s) {
         const uint32_t sbase = s * W;
@@ -111,7 +113,110 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
             const uint32_t sym = meta.sym;
             const uint32_t sym2 = sym | (sym << 16);
             const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
-            uint32_t PM[NP], PD[NP], PMl[Q];  // PMl: hi half = min over predecessors of M[p][my first column - 1]
+            uint32_t PMl[Q];  // hi half = min over predecessors of M[p][my first column - 1]
+            // the row itself, given the predecessor minima PM / PD; the chain path passes the previous row's
+            // registers themselves (no copies)
+            auto row_body = [&](const uint32_t (&PM)[NP], const uint32_t (&PD)[NP]) {
+                uint32_t Mc[NP], Ic[NP], Dc[NP], Hc[NP], PDe[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) PDe[p] = pk_add_sat(PD[p], e2);
+                if (meta.flags & ROW_END) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        Dc[p] = PDe[p];
+                        Mc[p] = pk_min(PM[p], Dc[p]);
+                        Ic[p] = inf2;
+                        Hc[p] = Mc[p];
+                    }
+                } else {
+                    // insertion-open rule, branch-free: "always" == the child symbol 0, which no query symbol equals
+                    // (past the query end q is 0 too: not open there, as the rule wants).  ROW_OPENI_NEVER only
+                    // occurs on the end row, handled above.
+                    const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
+                    const uint32_t csym2 = cs1 | (cs1 << 16);
+                    const uint32_t start_keep = ((meta.flags & ROW_START) && sbase == 0 && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                    uint32_t Tq[Q];
+#pragma unroll
+                    for (int m = 0; m < Q; ++m) {
+                        uint32_t eq_prev = ((qlE[m] >> 16) == sym) ? 0x00010000u : 0u;  // does the column left of the quad match? (hi half)
+                        uint32_t pm_prev = PMl[m];
+                        uint32_t t = I16;  // in-lane insertion chain (32-bit scalar in the 16-bit domain)
+                        uint32_t iloc[4];
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) {
+                            const int p = 4 * m + pp;
+                            const uint32_t eq1 = pk_is_zero(qP[p] ^ sym2);  // 1 where the query symbol equals the row's symbol
+                            // D: open a deletion only where the symbols differ (or past the query end, where q is 0)
+                            Dc[p] = pk_min(PDe[p], pk_inf_where(pk_add_sat(PM[p], oe2), eq1));
+                            const uint32_t pm_s = shr_col(PM[p], pm_prev);  // M of the predecessor(s), one column to the left
+                            const uint32_t eq_s = shr_col(eq1, eq_prev);
+                            // (mis)match from the left column: + x where the symbols differ (x - (eq << 8) saturates to 0 on a match)
+                            Hc[p] = pk_min(pk_add_sat(pm_s, pk_sub_sat(x2, pk_shl<8>(eq_s))), Dc[p]);
+                            pm_prev = PM[p]; eq_prev = eq1;
+                            if (m == 0 && pp == 0) Hc[p] &= start_keep;  // H[start][0] = 0
+                            // insertion open: A = (q != child symbol) ? H + oe : INF
+                            const uint32_t a = pk_inf_where(pk_add_sat(Hc[p], oe2), pk_is_zero(qP[p] ^ csym2));
+                            const uint32_t a_lo = a & 0xFFFFu, a_hi = a >> 16;
+                            const uint32_t i_lo = t;
+                            t = umin3(t + e, a_lo, I16);
+                            iloc[pp] = i_lo | (t << 16);
+                            t = umin3(t + e, a_hi, I16);
+                        }
+                        Tq[m] = t;
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = iloc[pp];
+                    }
+                    uint32_t cq = (s > 0) ? carry[2 * r] : I16;
+#pragma unroll
+                    for (int m = 0; m < Q; ++m) {
+                        const uint32_t Pm = wave_scan_min_plus16(Tq[m], step, w15, w31);
+                        const uint32_t excl = wave_shr1(Pm, I16);
+                        const uint32_t cin = umin3(excl, cq + lane_off, I16);
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
+                        cq = umin3(cq + QW * e, total, I16);
+                        const uint32_t cin2 = cin | (cin << 16);
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = pk_min(Ic[4 * m + pp], pk_add_sat(cin2, off2[pp]));
+                    }
+                    if (n_strips > 1 && lane == 0) carry[2 * r] = cq;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) Mc[p] = pk_min(Hc[p], Ic[p]);
+                }
+
+                // 4-bit codes (bit set == predicate holds): I==M, I[j]==I[j-1]+e, D==M, D==PD+e; 8 cells per dword, the
+                // nibble of my column k at position (k >> 1) + 4 * (k & 1)  (decoder: tb_code)
+                uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
+                const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+                uint32_t edge_i = inf2;
+                if (s > 0) edge_i = carry[2 * r + 1] << 16;
+#pragma unroll
+                for (int m = 0; m < Q; ++m) {
+                    uint32_t i_prev = pk_wave_shr1(Ic[4 * m + 3], edge_i);
+                    edge_i = (uint32_t)__builtin_amdgcn_readlane((int)Ic[4 * m + 3], 63);
+                    uint32_t fA = 0, fB = 0, fC = 0, fD = 0;  // flag of pair pp at bit 4*pp (even column) and 16 + 4*pp (odd column)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const int p = 4 * m + pp;
+                        const uint32_t i_left = shr_col(Ic[p], i_prev);
+                        i_prev = Ic[p];
+                        // equality flags (0/1 per half); in every pair below lhs >= rhs holds by construction
+                        fA |= pk_eq_ge(Ic[p], Mc[p]) << (4 * pp);                           // I == M   (M = min(H, I) <= I)
+                        fB |= pk_eq_ge(pk_add_sat(i_left, e2), Ic[p]) << (4 * pp);          // I[j] == I[j-1] + e
+                        fC |= pk_eq_ge(Dc[p], Mc[p]) << (4 * pp);                           // D == M   (M <= H <= D)
+                        fD |= pk_eq_ge(PDe[p], Dc[p]) << (4 * pp);                          // D == PD + e
+                    }
+                    const uint32_t word = fA | (fB << 1) | (fC << 2) | (fD << 3);
+                    if (act[m]) {
+                        *reinterpret_cast<uint4*>(Mp + rbase + m * QW) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
+                        if (keep_d)
+                            *reinterpret_cast<uint4*>(Dp + rbase + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
+                        codes[m * (QW / 8)] = word;
+                    }
+                }
+                if (n_strips > 1 && lane == 63) carry[2 * r + 1] = Ic[NP - 1] >> 16;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { Mprev[p] = Mc[p]; Dprev[p] = Dc[p]; }
+            };
 
             if (meta.flags & ROW_CHAIN) {
                 uint32_t edge = inf2;
@@ -121,9 +226,9 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
                     PMl[m] = pk_wave_shr1(Mprev[4 * m + 3], edge);
                     edge = (uint32_t)__builtin_amdgcn_readlane((int)Mprev[4 * m + 3], 63);
                 }
-#pragma unroll
-                for (int p = 0; p < NP; ++p) { PM[p] = Mprev[p]; PD[p] = Dprev[p]; }
+                row_body(Mprev, Dprev);
             } else {
+                uint32_t PM[NP], PD[NP];
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { PM[p] = inf2; PD[p] = inf2; }
 #pragma unroll
@@ -158,106 +263,8 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p) { PM[p] = pk_min(PM[p], tm[p]); PD[p] = pk_min(PD[p], td[p]); }
                 }
+                row_body(PM, PD);
             }
-
-            uint32_t Mc[NP], Ic[NP], Dc[NP], Hc[NP], PDe[NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) PDe[p] = pk_add_sat(PD[p], e2);
-            if (meta.flags & ROW_END) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    Dc[p] = PDe[p];
-                    Mc[p] = pk_min(PM[p], Dc[p]);
-                    Ic[p] = inf2;
-                    Hc[p] = Mc[p];
-                }
-            } else {
-                // insertion-open rule, branch-free: "always" == the child symbol 0, which no query symbol equals
-                // (past the query end q is 0 too: not open there, as the rule wants).  ROW_OPENI_NEVER only
-                // occurs on the end row, handled above.
-                const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
-                const uint32_t csym2 = cs1 | (cs1 << 16);
-                const uint32_t start_keep = ((meta.flags & ROW_START) && sbase == 0 && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
-                uint32_t Tq[Q];
-#pragma unroll
-                for (int m = 0; m < Q; ++m) {
-                    uint32_t mm_prev = ((qlE[m] >> 16) != sym) ? 0xFFFF0000u : 0u;  // mismatch of the column left of the quad (hi half)
-                    uint32_t pm_prev = PMl[m];
-                    uint32_t t = I16;  // in-lane insertion chain (32-bit scalar in the 16-bit domain)
-                    uint32_t iloc[4];
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) {
-                        const int p = 4 * m + pp;
-                        // 0xFFFF where the query symbol differs from the row's symbol
-                        const uint32_t mm = pk_sub(zero, pk_min(qP[p] ^ sym2, one2));
-                        Dc[p] = pk_min(PDe[p], pk_max(pk_add_sat(PM[p], oe2), ~mm));
-                        const uint32_t pm_s = shr_col(PM[p], pm_prev);  // M of the predecessor(s), one column to the left
-                        const uint32_t mm_s = shr_col(mm, mm_prev);
-                        Hc[p] = pk_min(pk_add_sat(pm_s, mm_s & x2), Dc[p]);
-                        pm_prev = PM[p]; mm_prev = mm;
-                        if (m == 0 && pp == 0) Hc[p] &= start_keep;  // H[start][0] = 0
-                        // insertion open: A = (q != child symbol) ? H + oe : INF
-                        const uint32_t a = pk_max(pk_add_sat(Hc[p], oe2), ~pk_sub(zero, pk_min(qP[p] ^ csym2, one2)));
-                        const uint32_t a_lo = a & 0xFFFFu, a_hi = a >> 16;
-                        const uint32_t i_lo = t;
-                        t = umin3(t + e, a_lo, I16);
-                        iloc[pp] = i_lo | (t << 16);
-                        t = umin3(t + e, a_hi, I16);
-                    }
-                    Tq[m] = t;
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = iloc[pp];
-                }
-                uint32_t cq = (s > 0) ? carry[2 * r] : I16;
-#pragma unroll
-                for (int m = 0; m < Q; ++m) {
-                    const uint32_t Pm = wave_scan_min_plus16(Tq[m], step, w15, w31);
-                    const uint32_t excl = wave_shr1(Pm, I16);
-                    const uint32_t cin = umin3(excl, cq + lane_off, I16);
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
-                    cq = umin3(cq + QW * e, total, I16);
-                    const uint32_t cin2 = cin | (cin << 16);
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = pk_min(Ic[4 * m + pp], pk_add_sat(cin2, off2[pp]));
-                }
-                if (n_strips > 1 && lane == 0) carry[2 * r] = cq;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) Mc[p] = pk_min(Hc[p], Ic[p]);
-            }
-
-            // 4-bit codes (bit set == predicate holds): I==M, I[j]==I[j-1]+e, D==M, D==PD+e; 8 cells per dword
-            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
-            const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
-            uint32_t edge_i = inf2;
-            if (s > 0) edge_i = carry[2 * r + 1] << 16;
-#pragma unroll
-            for (int m = 0; m < Q; ++m) {
-                uint32_t i_prev = pk_wave_shr1(Ic[4 * m + 3], edge_i);
-                edge_i = (uint32_t)__builtin_amdgcn_readlane((int)Ic[4 * m + 3], 63);
-                uint32_t word = 0;
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const int p = 4 * m + pp;
-                    const uint32_t i_left = shr_col(Ic[p], i_prev);
-                    i_prev = Ic[p];
-                    // "not equal" flags (0/1 per half); every pair below satisfies lhs >= rhs, so lhs -sat rhs == 0 <=> equal
-                    const uint32_t neA = pk_min(pk_sub_sat(Ic[p], Hc[p]), one2);                        // I == M  <=>  I <= H
-                    const uint32_t neB = pk_min(pk_sub_sat(pk_add_sat(i_left, e2), Ic[p]), one2);       // I[j] == I[j-1] + e
-                    const uint32_t neC = pk_min(pk_sub_sat(Dc[p], Mc[p]), one2);                        // D == M
-                    const uint32_t neD = pk_min(pk_sub_sat(PDe[p], Dc[p]), one2);                       // D == PD + e
-                    const uint32_t c = neA | (neB << 1) | (neC << 2) | (neD << 3);
-                    word |= ((c | (c >> 12)) & 0xFFu) << (8 * pp);
-                }
-                if (act[m]) {
-                    *reinterpret_cast<uint4*>(Mp + rbase + m * QW) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
-                    if (keep_d)
-                        *reinterpret_cast<uint4*>(Dp + rbase + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
-                    codes[m * (QW / 8)] = ~word;
-                }
-            }
-            if (n_strips > 1 && lane == 63) carry[2 * r + 1] = Ic[NP - 1] >> 16;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) { Mprev[p] = Mc[p]; Dprev[p] = Dc[p]; }
         }
         if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }

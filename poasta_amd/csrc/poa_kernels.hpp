@@ -178,7 +178,9 @@ __device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j
 
 template <typename T>
 __device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uint32_t j) {
-    return (c.codes[(uint64_t)row * (c.pitch / 8) + (j >> 3)] >> (4 * (j & 7))) & 0xFu;
+    // 8 cells per dword; the nibble of column k = j & 7 sits at position (k >> 1) + 4 * (k & 1)
+    const uint32_t k = j & 7u;
+    return (c.codes[(uint64_t)row * (c.pitch / 8) + (j >> 3)] >> (4 * ((k >> 1) + 4 * (k & 1)))) & 0xFu;
 }
 // gap_cs: the score of the current D / I cell, carried along the walk (compact layout has no I plane and
 // only some D rows; with full planes it equals the stored value and the stored value is used).
@@ -430,7 +432,8 @@ __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
 // other waves' HBM-bound forward work instead of running as a separate launch).
 // COMPACT (u16 planes only): the I plane is replaced by a 4-bit code per cell and D rows are written only where a
 // later row reads them back (ROW_STORE_D).  Codes, one nibble per cell, 8 cells per dword, row-major at the I plane's
-// place:  bit0 I==M   bit1 I[j]==I[j-1]+e   bit2 D==M   bit3 D==PD+e.  They are exactly the predicates the
+// place:  bit0 I==M   bit1 I[j]==I[j-1]+e   bit2 D==M   bit3 D==PD+e; within a dword the
+// nibble of column k (0..7) sits at position (k >> 1) + 4 * (k & 1).  They are exactly the predicates the
 // traceback evaluates on I and (for chain rows) D; see traceback_wave.
 template <int Q, typename T, bool FUSE_TB, bool COMPACT>
 __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(FwdParams P, TbParams TP) {
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                         nb |= (Ic[i] == sat_add(ip, e)) ? 2u : 0u;
                         nb |= (Dc[i] == Mc[i]) ? 4u : 0u;
                         nb |= (Dc[i] == sat_add(PD[i], e)) ? 8u : 0u;
-                        code |= nb << (4 * k);
+                        code |= nb << (4 * ((k >> 1) + 4 * (k & 1)));
                     }
                     if (act[m]) {
                         IO::store(Mp + rbase + m * QW, &Mc[K * m]);
