@@ -159,6 +159,9 @@ def main():
                          "kernel": "poa_forward_kernel<Q>", "avg_launch_ms": round(avg_launch_ms, 3),
                          "launches_timed": launches, "cells_per_launch": int(cells_per_launch),
                          "alg_bytes_per_cell": ALG_BYTES_PER_CELL,
+                         "note": "B_alg is fixed at 12 B/cell (the reference's three u32 score planes, SURVEY.md 8d); the "
+                                 "engine stores u16 M + 4-bit codes + partial D (~3 B/cell, see traffic), so frac > 1 is by "
+                                 "construction: the kernel is VALU-issue bound (DESIGN.md 6), not HBM bound",
                          "traceback_ms_per_step": round(st["ms_traceback"] / max(st["n_runs"], 1), 3)},
         }
         if world == 1 and args.cpu_sample > 0:

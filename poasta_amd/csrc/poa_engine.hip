@@ -76,13 +76,13 @@ struct poa_batch {
     DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
     DevBuf<uint2> d_scratch, d_pairs;
     // exact-replay mode (allocated on first use)
-    DevBuf<uint32_t> d_succ_off, d_succ_rows, d_dist_min, d_dist_max, d_nbm_off, d_ex_status, d_ex_rcnt, d_ex_head;
-    DevBuf<uint8_t> d_is_exit;
+    DevBuf<uint32_t> d_succ_off, d_succ_rows, d_dist_min, d_dist_max, d_nbm_off, d_ex_status, d_exit_idx, d_ex_head;
     DevBuf<FlatGraph::NodeBubble> d_nbm;
-    DevBuf<uint64_t> d_ex_reached;
+    DevBuf<uint8_t> d_ex_sym;
+    DevBuf<uint64_t> d_ex_reached, d_ex_rsum;
     DevBuf<ExQEntry> d_ex_pool;
     DevBuf<ExStackEntry> d_ex_stack;
-    uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0;
+    uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0, ex_swpn = 0;
     bool exact_ready = false;
     uint32_t last_mode = 0;
 
@@ -311,37 +311,43 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     const uint64_t pool64 = std::max<uint64_t>(256, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
     if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
     const uint32_t n_prio = (uint32_t)n_prio64, pool_cap = (uint32_t)pool64;
-    const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64);
+    const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64), swpn = (wpn + 63) / 64;
     if (b->exact_ready && b->ex_n_prio >= n_prio && b->ex_pool_cap >= pool_cap) return POA_OK;
     const uint64_t slots = b->max_chunk;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t need = slots * ((uint64_t)n * wpn * 8 + (uint64_t)n * 4 + 3ull * n_prio * 4 + (uint64_t)stack_cap * 12 + (uint64_t)pool_cap * 16);
+    const uint64_t need = slots * ((uint64_t)fg.n_exit * (wpn + swpn) * 8 + 3ull * n_prio * 4 + (uint64_t)stack_cap * 12 + (uint64_t)pool_cap * 16);
     if (need + (256ull << 20) > free_b + b->d_ex_pool.n * 16 + b->d_ex_head.n * 4 + b->d_ex_reached.n * 8)
         return fail(POA_ERR_OUT_OF_MEMORY, "exact replay workspace does not fit: create the batch with a smaller workspace_bytes (fewer queries per chunk) or lower queue_entries_per_cell");
     if (!b->exact_ready) {
         HIP_TRY(b->d_succ_off.alloc(fg.succ_row_off.size()));
         HIP_TRY(b->d_succ_rows.alloc(std::max<size_t>(fg.succ_rows.size(), 1)));
-        HIP_TRY(b->d_dist_min.alloc(n)); HIP_TRY(b->d_dist_max.alloc(n)); HIP_TRY(b->d_is_exit.alloc(n));
+        HIP_TRY(b->d_dist_min.alloc(n)); HIP_TRY(b->d_dist_max.alloc(n)); HIP_TRY(b->d_exit_idx.alloc(n));
+        HIP_TRY(b->d_ex_sym.alloc((size_t)n + 4));
+        {
+            std::vector<uint8_t> row_sym((size_t)n + 4, 0);
+            for (uint32_t r = 0; r < n; ++r) row_sym[r] = fg.rows[r].sym;
+            HIP_TRY(hipMemcpy(b->d_ex_sym.p, row_sym.data(), row_sym.size(), hipMemcpyHostToDevice));
+        }
         HIP_TRY(b->d_nbm_off.alloc(n + 1)); HIP_TRY(b->d_nbm.alloc(std::max<size_t>(fg.nbm.size(), 1)));
         HIP_TRY(b->d_ex_status.alloc(std::max<uint32_t>(b->n_queries, 1)));
         HIP_TRY(hipMemcpy(b->d_succ_off.p, fg.succ_row_off.data(), fg.succ_row_off.size() * 4, hipMemcpyHostToDevice));
         if (!fg.succ_rows.empty()) HIP_TRY(hipMemcpy(b->d_succ_rows.p, fg.succ_rows.data(), fg.succ_rows.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_dist_min.p, fg.dist_min.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_dist_max.p, fg.dist_max.data(), n * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_is_exit.p, fg.is_exit.data(), n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_exit_idx.p, fg.exit_idx.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_nbm_off.p, fg.nbm_off.data(), (n + 1) * 4, hipMemcpyHostToDevice));
         if (!fg.nbm.empty()) HIP_TRY(hipMemcpy(b->d_nbm.p, fg.nbm.data(), fg.nbm.size() * sizeof(FlatGraph::NodeBubble), hipMemcpyHostToDevice));
     }
-    HIP_TRY(b->d_ex_reached.alloc(slots * n * wpn));
-    HIP_TRY(b->d_ex_rcnt.alloc(slots * n));
+    HIP_TRY(b->d_ex_reached.alloc(std::max<uint64_t>(slots * fg.n_exit * wpn, 1)));
+    HIP_TRY(b->d_ex_rsum.alloc(std::max<uint64_t>(slots * fg.n_exit * swpn, 1)));
     HIP_TRY(b->d_ex_head.alloc(slots * 3 * n_prio));
     HIP_TRY(b->d_ex_stack.alloc(slots * stack_cap));
     {
         hipError_t e = b->d_ex_pool.alloc(slots * pool_cap);
         if (e != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, std::string("exact replay queue pool: ") + hipGetErrorString(e));
     }
-    b->ex_n_prio = n_prio; b->ex_pool_cap = pool_cap; b->ex_stack_cap = stack_cap; b->ex_wpn = wpn;
+    b->ex_n_prio = n_prio; b->ex_pool_cap = pool_cap; b->ex_stack_cap = stack_cap; b->ex_wpn = wpn; b->ex_swpn = swpn;
     b->exact_ready = true;
     return POA_OK;
 }
@@ -459,28 +465,48 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             hipLaunchKernelGGL(poa_fill_planes_kernel, dim3(64, ch.count), dim3(256), 0, stream, b->d_planes.p, b->d_plane_off.p,
                                b->d_pitch.p, fg.n, ch.first, hybrid, b->d_flags.p);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemsetAsync(b->d_ex_reached.p, 0, (size_t)ch.count * fg.n * b->ex_wpn * 8, stream));
-            HIP_TRY(hipMemsetAsync(b->d_ex_rcnt.p, 0, (size_t)ch.count * fg.n * 4, stream));
+            if (fg.n_exit) {
+                HIP_TRY(hipMemsetAsync(b->d_ex_reached.p, 0, (size_t)ch.count * fg.n_exit * b->ex_wpn * 8, stream));
+                HIP_TRY(hipMemsetAsync(b->d_ex_rsum.p, 0, (size_t)ch.count * fg.n_exit * b->ex_swpn * 8, stream));
+            }
             HIP_TRY(hipMemsetAsync(b->d_ex_head.p, 0xFF, (size_t)ch.count * 3 * b->ex_n_prio * 4, stream));
             ExactParams ep;
-            ep.G = ExactGraph{fg.n, fg.start_row, fg.end_row, b->d_rows.p, b->d_succ_off.p, b->d_succ_rows.p, b->d_dist_min.p,
-                              b->d_dist_max.p, b->d_is_exit.p, b->d_nbm_off.p, b->d_nbm.p};
+            ep.G = ExactGraph{fg.n, fg.start_row, fg.end_row, b->d_ex_sym.p, b->d_succ_off.p, b->d_succ_rows.p, b->d_dist_min.p,
+                              b->d_dist_max.p, b->d_exit_idx.p, fg.n_exit, b->d_nbm_off.p, b->d_nbm.p};
             ep.first_query = ch.first; ep.n_queries = ch.count; ep.hybrid = hybrid; ep.dense_flags = b->d_flags.p;
             ep.qseq = b->d_qseq.p; ep.qoff = b->d_qoff.p; ep.pitch = b->d_pitch.p; ep.plane_off = b->d_plane_off.p;
             ep.planes = b->d_planes.p;
-            ep.reached = b->d_ex_reached.p; ep.reached_stride = (uint64_t)fg.n * b->ex_wpn; ep.rcnt = b->d_ex_rcnt.p;
+            ep.reached = b->d_ex_reached.p; ep.rsum = b->d_ex_rsum.p; ep.wpn = b->ex_wpn; ep.swpn = b->ex_swpn;
             ep.head = b->d_ex_head.p; ep.n_prio = b->ex_n_prio; ep.pool = b->d_ex_pool.p; ep.pool_cap = b->ex_pool_cap;
             ep.stack = b->d_ex_stack.p; ep.stack_cap = b->ex_stack_cap;
             ep.C = ExactCosts{costs->mismatch, costs->gap_open, costs->gap_extend, cfg ? cfg->heuristic : POA_HEURISTIC_MINGAP,
                               cfg ? cfg->pruning : 1u};
             ep.status = b->d_ex_status.p;
             // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
-            // waves; enough waves to fill the chip (~20 per CU) first, then more lanes per wave.
+            // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.
             uint32_t lanes = (ch.count + 4095) / 4096;
             if (lanes > 64) lanes = 64;
             if (const char* lv = getenv("POA_EXACT_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
             ep.lanes_per_wave = lanes;
-            hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + lanes - 1) / lanes), dim3(64), 0, stream, ep);
+            ep.n_succ = (uint32_t)fg.succ_rows.size(); ep.n_nbm = (uint32_t)fg.nbm.size();
+            // graph arrays in LDS when they fit beside three other blocks of the same CU (160 KB per CU)
+            uint32_t lds_bytes = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
+            bool lds_graph = lds_bytes <= 160u * 1024u / 3u;
+            if (const char* gv = getenv("POA_EXACT_LDS")) lds_graph = lds_graph && atoi(gv) != 0;
+            if (lds_graph && lds_bytes > 48u * 1024u)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(poa_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            ep.lds_graph = lds_graph ? 1u : 0u;
+            if (lds_graph && !getenv("POA_EXACT_LANES")) {
+                // all blocks resident at once (no tail round): LDS bounds the blocks per CU
+                int cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+                const uint32_t per_cu = std::max(1u, std::min(8u, 160u * 1024u / std::max(lds_bytes, 1u)));
+                const uint32_t cap_waves = (uint32_t)cus * per_cu * (EXACT_BLOCK / 64);
+                lanes = std::min(64u, std::max(lanes, (ch.count + cap_waves - 1) / cap_waves));
+                ep.lanes_per_wave = lanes;
+            }
+            const uint32_t per_block = lanes * (EXACT_BLOCK / 64);
+            hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + per_block - 1) / per_block), dim3(EXACT_BLOCK), lds_graph ? lds_bytes : 0, stream, ep);
             HIP_TRY(hipGetLastError());
             tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p;
             hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);

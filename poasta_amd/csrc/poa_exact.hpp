@@ -39,12 +39,13 @@ constexpr uint32_t EX_NIL = 0xFFFFFFFFu;
 
 struct ExactGraph {  // row-indexed, read-only, shared by all queries
     uint32_t n_rows, start_row, end_row;
-    const RowMeta* rows;
+    const uint8_t* sym;        // [n_rows] node symbol
     const uint32_t* succ_off;  // [n_rows+1]
     const uint32_t* succ;      // successor rows in trait iteration order
     const uint32_t* dist_min;
     const uint32_t* dist_max;
-    const uint8_t* is_exit;
+    const uint32_t* exit_idx;  // [n_rows] index among the bubble-exit rows, EX_NIL for the others
+    uint32_t n_exit;
     const uint32_t* nbm_off;   // [n_rows+1]
     const FlatGraph::NodeBubble* nbm;
 };
@@ -55,9 +56,9 @@ struct ExStackEntry { uint32_t row, offset, it; };
 struct ExactWork {  // per query
     uint32_t* M; uint32_t* I; uint32_t* D;  // visited planes [row * pitch + offset], INF-initialised
     uint32_t pitch;
-    uint64_t* reached;      // [n_rows * wpn] bitset of offsets reached in Match state (exit rows only)
-    uint32_t* reached_cnt;  // [n_rows]
-    uint32_t wpn;
+    uint64_t* reached;      // [n_exit * wpn] bitset of offsets reached in Match state, one row per bubble exit
+    uint64_t* rsum;         // [n_exit * swpn] summary: bit w set iff word w of that exit's bitset is non-zero
+    uint32_t wpn, swpn;
     uint32_t* head;         // [3 * n_prio] LIFO heads per (priority, state): M, D, I
     uint32_t n_prio;
     ExQEntry* pool; uint32_t pool_cap;
@@ -99,7 +100,7 @@ public:
         return (st == EX_ST_M ? (uint64_t)C.o : 0) + length * (uint64_t)C.e;
     }
     POA_HD bool is_symbol_equal(uint32_t row, uint8_t c) const {  // graphs/poa.rs:463-465
-        return row == G.end_row || G.rows[row].sym == c;
+        return row == G.end_row || G.sym[row] == c;
     }
 
     // ---- visited table (gap_affine.rs:483-548) -----------------------------------------------
@@ -114,37 +115,67 @@ public:
         return false;
     }
 
-    // ---- reached sets: BTreeSet<offset> per exit node as a bitset (gap_affine.rs:711,:767-773) ---
+    // ---- reached sets: BTreeSet<offset> per exit node as a two-level bitset (gap_affine.rs:711,:767-773) ---
     POA_HD void mark_reached(uint32_t row, uint32_t off, uint32_t st) {
-        if (st != EX_ST_M || !G.is_exit[row]) return;
-        uint64_t* w = W.reached + (uint64_t)row * W.wpn + (off >> 6);
-        const uint64_t bit = 1ull << (off & 63);
-        if (!(*w & bit)) { *w |= bit; W.reached_cnt[row]++; }
+        if (st != EX_ST_M) return;
+        const uint32_t x = G.exit_idx[row];
+        if (x == EX_NIL) return;
+        const uint32_t wi = off >> 6;
+        uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
+        const uint64_t old = *w;
+        *w = old | (1ull << (off & 63));
+        if (old == 0) W.rsum[(uint64_t)x * W.swpn + (wi >> 6)] |= 1ull << (wi & 63);
     }
-    // largest reached offset < t, or EX_NIL
+    POA_HD bool reached_any(uint32_t row) const {  // !reached_offsets.is_empty()
+        const uint64_t* s = W.rsum + (uint64_t)G.exit_idx[row] * W.swpn;
+        for (uint32_t i = 0; i < W.swpn; ++i) if (s[i]) return true;
+        return false;
+    }
+    // largest reached offset < t, or EX_NIL  (row must be an exit row)
     POA_HD uint32_t reached_before(uint32_t row, uint32_t t) const {
         if (t == 0) return EX_NIL;
-        const uint64_t* b = W.reached + (uint64_t)row * W.wpn;
+        const uint32_t x = G.exit_idx[row];
+        const uint64_t* b = W.reached + (uint64_t)x * W.wpn;
+        const uint64_t* s = W.rsum + (uint64_t)x * W.swpn;
         uint32_t last = t - 1;
         if ((last >> 6) >= W.wpn) last = W.wpn * 64 - 1;
-        int32_t wi = (int32_t)(last >> 6);
-        uint64_t w = b[wi] & (~0ull >> (63 - (last & 63)));
+        const uint32_t wi = last >> 6;
+        const uint64_t w = b[wi] & (~0ull >> (63 - (last & 63)));
+        if (w) return wi * 64 + 63 - (uint32_t)clz64(w);
+        if (wi == 0) return EX_NIL;
+        // non-empty words below wi, through the summary
+        const uint32_t lw = wi - 1;
+        int32_t si = (int32_t)(lw >> 6);
+        uint64_t sw = s[si] & (~0ull >> (63 - (lw & 63)));
         for (;;) {
-            if (w) return (uint32_t)wi * 64 + 63 - (uint32_t)clz64(w);
-            if (--wi < 0) return EX_NIL;
-            w = b[wi];
+            if (sw) {
+                const uint32_t fw = (uint32_t)si * 64 + 63 - (uint32_t)clz64(sw);
+                return fw * 64 + 63 - (uint32_t)clz64(b[fw]);
+            }
+            if (--si < 0) return EX_NIL;
+            sw = s[si];
         }
     }
-    // smallest reached offset >= t, or EX_NIL
+    // smallest reached offset >= t, or EX_NIL  (row must be an exit row)
     POA_HD uint32_t reached_from(uint32_t row, uint32_t t) const {
-        uint32_t wi = t >> 6;
+        const uint32_t wi = t >> 6;
         if (wi >= W.wpn) return EX_NIL;
-        const uint64_t* b = W.reached + (uint64_t)row * W.wpn;
-        uint64_t w = b[wi] & (~0ull << (t & 63));
+        const uint32_t x = G.exit_idx[row];
+        const uint64_t* b = W.reached + (uint64_t)x * W.wpn;
+        const uint64_t* s = W.rsum + (uint64_t)x * W.swpn;
+        const uint64_t w = b[wi] & (~0ull << (t & 63));
+        if (w) return wi * 64 + (uint32_t)ctz64(w);
+        const uint32_t nw = wi + 1;
+        if (nw >= W.wpn) return EX_NIL;
+        uint32_t si = nw >> 6;
+        uint64_t sw = s[si] & (~0ull << (nw & 63));
         for (;;) {
-            if (w) return wi * 64 + (uint32_t)ctz64(w);
-            if (++wi >= W.wpn) return EX_NIL;
-            w = b[wi];
+            if (sw) {
+                const uint32_t fw = si * 64 + (uint32_t)ctz64(sw);
+                return fw * 64 + (uint32_t)ctz64(b[fw]);
+            }
+            if (++si >= W.swpn) return EX_NIL;
+            sw = s[si];
         }
     }
     static POA_HD int clz64(uint64_t v) {
@@ -203,7 +234,7 @@ public:
 
     POA_HD bool can_improve_bubble(const FlatGraph::NodeBubble& b, uint32_t row, uint32_t off, uint32_t st, uint32_t current) {
         const uint32_t ex = b.exit_row;
-        if (W.reached_cnt[ex] == 0) return true;
+        if (!reached_any(ex)) return true;
         if (row == ex) return true;
         const uint32_t tmin = off + b.min_dist, tmax = off + b.max_dist;
         uint64_t mde = G.dist_min[ex]; mde = mde ? mde - 1 : 0;

@@ -19,20 +19,57 @@ struct ExactParams {
     const uint32_t* pitch;
     const uint64_t* plane_off;
     uint32_t* planes;                 // u32 layout, INF-filled for the selected queries
-    uint64_t* reached; uint64_t reached_stride;   // per slot (u64 words)
-    uint32_t* rcnt;                   // per slot: n_rows
+    uint64_t* reached;                // per slot: n_exit * wpn words
+    uint64_t* rsum;                   // per slot: n_exit * swpn words
+    uint32_t wpn, swpn;               // sized for the longest query of the batch
     uint32_t* head; uint32_t n_prio;  // per slot: 3 * n_prio
     ExQEntry* pool; uint32_t pool_cap;
     ExStackEntry* stack; uint32_t stack_cap;
     ExactCosts C;
     uint32_t* status;                 // [total] EX_* (0xFFFFFFFF = not replayed)
     uint32_t lanes_per_wave;          // active lanes per wave (divergence vs occupancy knob)
+    uint32_t lds_graph;               // 1: the launch carries enough dynamic LDS to hold the graph arrays
+    uint32_t n_succ, n_nbm;           // lengths of G.succ / G.nbm
 };
 
-__global__ __launch_bounds__(64) void poa_exact_kernel(ExactParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
+// bytes of dynamic LDS the graph arrays need (each array padded to 16 bytes)
+__host__ __device__ inline uint32_t exact_lds_bytes(uint32_t n_rows, uint32_t n_succ, uint32_t n_nbm) {
+    auto pad = [](uint64_t b) { return (uint32_t)((b + 15) & ~15ull); };
+    return pad(n_rows) + 2 * pad(4ull * (n_rows + 1)) + pad(4ull * n_succ) + 3 * pad(4ull * n_rows) +
+           pad(sizeof(FlatGraph::NodeBubble) * (uint64_t)n_nbm);
+}
+
+constexpr int EXACT_BLOCK = 256;  // 4 waves share one LDS copy of the graph
+
+__global__ __launch_bounds__(EXACT_BLOCK) void poa_exact_kernel(ExactParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    ExactGraph G = P.G;
+    if (P.lds_graph) {
+        // every search of the block reads the same graph: stage its arrays in LDS once (latency, not bandwidth, bounds
+        // the search, and an LDS read is an order of magnitude closer than an L2 hit)
+        uint32_t at = 0;
+        auto stage = [&](const void* src, uint64_t bytes) {
+            uint8_t* dst = lds + at;
+            const uint32_t words = (uint32_t)((bytes + 3) / 4);
+            const uint32_t* s32 = static_cast<const uint32_t*>(src);
+            for (uint32_t i = threadIdx.x; i < words; i += EXACT_BLOCK) reinterpret_cast<uint32_t*>(dst)[i] = s32[i];
+            at += (uint32_t)((bytes + 15) & ~15ull);
+            return dst;
+        };
+        const uint32_t n = P.G.n_rows;
+        G.sym = stage(P.G.sym, n);
+        G.succ_off = reinterpret_cast<const uint32_t*>(stage(P.G.succ_off, 4ull * (n + 1)));
+        G.nbm_off = reinterpret_cast<const uint32_t*>(stage(P.G.nbm_off, 4ull * (n + 1)));
+        G.succ = reinterpret_cast<const uint32_t*>(stage(P.G.succ, 4ull * P.n_succ));
+        G.dist_min = reinterpret_cast<const uint32_t*>(stage(P.G.dist_min, 4ull * n));
+        G.dist_max = reinterpret_cast<const uint32_t*>(stage(P.G.dist_max, 4ull * n));
+        G.exit_idx = reinterpret_cast<const uint32_t*>(stage(P.G.exit_idx, 4ull * n));
+        G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(P.G.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)P.n_nbm));
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane >= P.lanes_per_wave) return;
-    const uint32_t slot = blockIdx.x * P.lanes_per_wave + lane;
+    const uint32_t slot = (blockIdx.x * (EXACT_BLOCK / 64) + wave) * P.lanes_per_wave + lane;
     if (slot >= P.n_queries) return;
     const uint32_t qi = P.first_query + slot;
     if (P.hybrid && P.dense_flags[qi] == 0) return;
@@ -45,16 +82,16 @@ __global__ __launch_bounds__(64) void poa_exact_kernel(ExactParams P) {
     W.I = W.M + RP;
     W.D = W.I + RP;
     W.pitch = pitch;
-    W.reached = P.reached + (uint64_t)slot * P.reached_stride;
-    W.reached_cnt = P.rcnt + (uint64_t)slot * P.G.n_rows;
-    W.wpn = (L + 1 + 63) / 64;
+    W.reached = P.reached + (uint64_t)slot * P.G.n_exit * P.wpn;
+    W.rsum = P.rsum + (uint64_t)slot * P.G.n_exit * P.swpn;
+    W.wpn = P.wpn; W.swpn = P.swpn;
     W.head = P.head + (uint64_t)slot * 3 * P.n_prio;
     W.n_prio = P.n_prio;
     W.pool = P.pool + (uint64_t)slot * P.pool_cap;
     W.pool_cap = P.pool_cap;
     W.stack = P.stack + (uint64_t)slot * P.stack_cap;
     W.stack_cap = P.stack_cap;
-    ExactSearch S(P.G, W, P.qseq + qbeg, L, P.C);
+    ExactSearch S(G, W, P.qseq + qbeg, L, P.C);
     const ExactResult R = S.run();
     P.status[qi] = R.status;
 }

@@ -158,6 +158,7 @@ int build_bubble_index(FlatGraph& g, std::string& err) {
         g.succ_row_off[r + 1] = (uint32_t)g.succ_rows.size();
     }
     g.dist_min.assign(n, 0); g.dist_max.assign(n, 0); g.is_exit.assign(n, 0);
+    g.exit_idx.assign(n, 0xFFFFFFFFu); g.n_exit = 0;
     g.nbm_off.assign(n + 1, 0); g.nbm.clear();
     if (n == 2) { g.bubbles_built = true; return POA_OK; }
 
@@ -278,6 +279,9 @@ int build_bubble_index(FlatGraph& g, std::string& err) {
         for (auto& b : nbm[v]) g.nbm.push_back({g.node_row[b.exit_row], b.min_dist, b.max_dist});
     }
     g.nbm_off[n] = (uint32_t)g.nbm.size();
+    g.exit_idx.assign(n, 0xFFFFFFFFu);
+    g.n_exit = 0;
+    for (uint32_t r = 0; r < n; ++r) if (g.is_exit[r]) g.exit_idx[r] = g.n_exit++;
     g.bubbles_built = true;
     return POA_OK;
 }

@@ -48,6 +48,8 @@ struct FlatGraph {
     // BubbleIndex (src/bubbles/index.rs:33-45), indexed by ROW
     std::vector<uint32_t> dist_min, dist_max;     // dist_to_end (min, max)
     std::vector<uint8_t> is_exit;                 // bubble_exit[node].is_exit()
+    std::vector<uint32_t> exit_idx;               // row -> index among the exit rows (0xFFFFFFFF: not an exit)
+    uint32_t n_exit = 0;
     struct NodeBubble { uint32_t exit_row, min_dist, max_dist; };
     std::vector<uint32_t> nbm_off;                // [n+1]
     std::vector<NodeBubble> nbm;                  // node_bubble_map flattened, per-node order preserved

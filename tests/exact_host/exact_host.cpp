@@ -26,17 +26,18 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     if (rc != POA_OK) return rc;
     rc = build_bubble_index(g, err);
     if (rc != POA_OK) return rc;
-    ExactGraph G{g.n, g.start_row, g.end_row, g.rows.data(), g.succ_row_off.data(), g.succ_rows.data(),
-                 g.dist_min.data(), g.dist_max.data(), g.is_exit.data(), g.nbm_off.data(), g.nbm.data()};
-    const uint32_t pitch = len + 1, wpn = (len + 1 + 63) / 64;
+    std::vector<uint8_t> row_sym(g.n);
+    for (uint32_t r = 0; r < g.n; ++r) row_sym[r] = g.rows[r].sym;
+    ExactGraph G{g.n, g.start_row, g.end_row, row_sym.data(), g.succ_row_off.data(), g.succ_rows.data(),
+                 g.dist_min.data(), g.dist_max.data(), g.exit_idx.data(), g.n_exit, g.nbm_off.data(), g.nbm.data()};
+    const uint32_t pitch = len + 1, wpn = (len + 1 + 63) / 64, swpn = (wpn + 63) / 64;
     std::vector<uint32_t> M((size_t)n * pitch, EX_INF), I(M), D(M);
-    std::vector<uint64_t> reached((size_t)n * wpn, 0);
-    std::vector<uint32_t> rcnt(n, 0);
+    std::vector<uint64_t> reached((size_t)g.n_exit * wpn + 1, 0), rsum((size_t)g.n_exit * swpn + 1, 0);
     const uint32_t n_prio = (n + len + 2) * std::max<uint32_t>(x, (uint32_t)o + e) + 2 * ((uint32_t)o + (n + len) * e) + 64;
     std::vector<uint32_t> head((size_t)3 * n_prio, EX_NIL);
     std::vector<ExQEntry> pool((size_t)4 * n * pitch + 1024);
     std::vector<ExStackEntry> stack(n + len + 8);
-    ExactWork W{M.data(), I.data(), D.data(), pitch, reached.data(), rcnt.data(), wpn, head.data(), n_prio,
+    ExactWork W{M.data(), I.data(), D.data(), pitch, reached.data(), rsum.data(), wpn, swpn, head.data(), n_prio,
                 pool.data(), (uint32_t)pool.size(), stack.data(), (uint32_t)stack.size()};
     ExactSearch S(G, W, seq, len, ExactCosts{x, o, e, (uint32_t)heuristic, (uint32_t)prune});
     ExactResult R = S.run();
