@@ -60,10 +60,20 @@ struct poa_batch {
     uint64_t total_bases = 0, total_cells = 0, plane_bytes_total = 0;
     std::vector<uint64_t> h_qoff;
     std::vector<uint32_t> h_pitch;
-    std::vector<uint64_t> h_plane_off, h_scratch_off;
+    std::vector<uint64_t> h_scratch_off;
     struct Chunk { uint32_t first, count; };
-    std::vector<Chunk> chunks;
-    uint32_t max_chunk = 0;
+    // How the queries share the plane workspace.  plan[0]: 4-byte elements (u32 planes, exact replay);
+    // plan[1]: 2-byte elements (u16 / compact layouts) — twice the queries per chunk when the batch needs chunks.
+    struct Plan {
+        std::vector<Chunk> chunks;
+        std::vector<uint64_t> off;   // per query: offset of its planes in ELEMENTS of the layout's type
+        uint32_t max_chunk = 0;
+        DevBuf<uint64_t> d_off;
+    };
+    Plan plan[2];
+    bool plan16_same = true;         // plan[1] not built: everything fits in one chunk anyway
+    int active_plan = 0;             // plan of the last run
+    const Plan& cur() const { return plan[active_plan]; }
     uint64_t max_len = 0;
     bool narrow = false;  // last run used u16 planes
     bool compact = false; // last run used the compact layout (no I plane, partial D)
@@ -72,7 +82,7 @@ struct poa_batch {
     DevBuf<RowMeta> d_rows;
     DevBuf<uint32_t> d_pred_rows;
     DevBuf<uint8_t> d_qseq;
-    DevBuf<uint64_t> d_qoff, d_plane_off, d_scratch_off, d_pair_off;
+    DevBuf<uint64_t> d_qoff, d_scratch_off, d_pair_off;
     DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
     DevBuf<uint2> d_scratch, d_pairs;
     // exact-replay mode (allocated on first use)
@@ -104,7 +114,7 @@ static void collect_stats(poa_batch* b, poa_stats_t* stats) {
     const uint32_t n = b->n_queries;
     const uint32_t keep_flagged = stats->n_flagged;
     stats->cells = b->total_cells; stats->bases = b->total_bases; stats->plane_bytes = b->plane_bytes_total;
-    stats->n_queries = n; stats->n_chunks = (uint32_t)b->chunks.size();
+    stats->n_queries = n; stats->n_chunks = (uint32_t)b->cur().chunks.size();
     stats->n_flagged = keep_flagged;
     stats->ms_h2d = b->ms_h2d; stats->ms_d2h = 0.f;
     float fwd = 0.f, tb = 0.f, ex = 0.f, total = 0.f;
@@ -113,7 +123,8 @@ static void collect_stats(poa_batch* b, poa_stats_t* stats) {
         if (n) {
             size_t ev = 1;
             hipEvent_t prev = events[0];
-            for (size_t c = 0; c < b->chunks.size(); ++c) {
+            const size_t n_chunks = (events.size() - 2) / 3;
+            for (size_t c = 0; c < n_chunks; ++c) {
                 float a = 0.f, t2 = 0.f, t3 = 0.f;
                 (void)hipEventElapsedTime(&a, prev, events[ev]);
                 (void)hipEventElapsedTime(&t2, events[ev], events[ev + 1]);
@@ -197,7 +208,6 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     try {
         b->h_qoff.assign(qoff, qoff + n_queries + 1);
         b->h_pitch.resize(n_queries);
-        b->h_plane_off.resize(n_queries);
         b->h_scratch_off.resize((size_t)n_queries + 1);
     } catch (const std::bad_alloc&) { return fail(POA_ERR_OUT_OF_MEMORY, "host allocation failed"); }
 
@@ -236,22 +246,27 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
             ws = biggest;
         }
     }
-    // greedy chunking
-    {
+    // greedy chunking, once per element size
+    auto make_plan = [&](poa_batch::Plan& pl, uint64_t elem_bytes) {
+        pl.off.resize(n_queries);
         uint32_t first = 0;
         uint64_t used = 0;
         for (uint32_t i = 0; i < n_queries; ++i) {
-            const uint64_t need = q_plane_elems[i] * 4;
+            const uint64_t need = q_plane_elems[i] * elem_bytes;
             if (used + need > ws && i > first) {
-                b->chunks.push_back({first, i - first});
+                pl.chunks.push_back({first, i - first});
                 first = i; used = 0;
             }
-            b->h_plane_off[i] = used / 4;
+            pl.off[i] = used / elem_bytes;
             used += need;
         }
-        if (n_queries > first) b->chunks.push_back({first, n_queries - first});
-        for (auto& c : b->chunks) b->max_chunk = std::max(b->max_chunk, c.count);
-    }
+        if (n_queries > first) pl.chunks.push_back({first, n_queries - first});
+        for (auto& c : pl.chunks) pl.max_chunk = std::max(pl.max_chunk, c.count);
+    };
+    make_plan(b->plan[0], 4);
+    b->plan16_same = b->plan[0].chunks.size() <= 1;
+    if (!b->plan16_same) make_plan(b->plan[1], 2);
+    const uint32_t max_chunk_any = std::max(b->plan[0].max_chunk, b->plan[1].max_chunk);
     b->cols_per_lane = 16;
 
     // device buffers
@@ -260,7 +275,7 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(b->d_qseq.alloc(std::max<uint64_t>(qoff[n_queries], 1)));
     HIP_TRY(b->d_qoff.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_pitch.alloc(std::max<uint32_t>(n_queries, 1)));
-    HIP_TRY(b->d_plane_off.alloc(std::max<uint32_t>(n_queries, 1)));
+    for (int k = 0; k < (b->plan16_same ? 1 : 2); ++k) HIP_TRY(b->plan[k].d_off.alloc(std::max<uint32_t>(n_queries, 1)));
     HIP_TRY(b->d_scratch_off.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_pair_off.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_score.alloc(std::max<uint32_t>(n_queries, 1)));
@@ -268,7 +283,7 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(b->d_npairs.alloc(std::max<uint32_t>(n_queries, 1)));
     HIP_TRY(b->d_scratch.alloc(std::max<uint64_t>(scratch_total, 1)));
     HIP_TRY(b->d_pairs.alloc(std::max<uint64_t>(scratch_total, 1)));
-    HIP_TRY(b->d_carry.alloc(std::max<uint64_t>(2ull * b->max_chunk * rows, 1)));
+    HIP_TRY(b->d_carry.alloc(std::max<uint64_t>(2ull * max_chunk_any * rows, 1)));
     if (n_queries) {
         hipError_t e = b->d_planes.alloc(ws / 4 + 64);
         if (e != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, std::string("score-plane workspace: ") + hipGetErrorString(e));
@@ -286,7 +301,8 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(hipMemcpy(b->d_scratch_off.p, b->h_scratch_off.data(), ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
     if (n_queries) {
         HIP_TRY(hipMemcpy(b->d_pitch.p, b->h_pitch.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_plane_off.p, b->h_plane_off.data(), (size_t)n_queries * 8, hipMemcpyHostToDevice));
+        for (int k = 0; k < (b->plan16_same ? 1 : 2); ++k)
+            HIP_TRY(hipMemcpy(b->plan[k].d_off.p, b->plan[k].off.data(), (size_t)n_queries * 8, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
@@ -313,7 +329,7 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     const uint32_t n_prio = (uint32_t)n_prio64, pool_cap = (uint32_t)pool64;
     const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64), swpn = (wpn + 63) / 64;
     if (b->exact_ready && b->ex_n_prio >= n_prio && b->ex_pool_cap >= pool_cap) return POA_OK;
-    const uint64_t slots = b->max_chunk;
+    const uint64_t slots = b->plan[0].max_chunk;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t need = slots * ((uint64_t)fg.n_exit * (wpn + swpn) * 8 + 3ull * n_prio * 4 + (uint64_t)stack_cap * 12 + (uint64_t)pool_cap * 16);
@@ -369,10 +385,38 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     b->last_mode = mode;
     b->last_stream = stream;
     if (b->runs.size() >= 256) return fail(POA_ERR_UNSUPPORTED, "poa_batch_run: call poa_batch_stats/fetch at least every 256 runs");
+    // u16 planes whenever every value that can matter fits.  u16 arithmetic saturates at 0xFFFF = INF, so every stored
+    // value is min(true value, 0xFFFF); costs are non-negative, hence every cell on an optimal path — and every
+    // predecessor candidate the traceback can accept — has a value <= the final score, and the final score is at most
+    //     ub = [o + e*L] + [o + e*(nodes on the shortest start->end path)]      (insert the query, delete that path).
+    // ub <= 65534  =>  everything the result depends on is exact in u16.  (The cruder bound (rows + L + 2) * max(x, o+e)
+    // on ANY finite value is always >= ub.)  POA_PLANES=32 forces u32 (debug / A-B).
+    const uint64_t ub = (b->max_len ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * b->max_len : 0) +
+                        (fg.min_path_nodes ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * fg.min_path_nodes : 0);
+    bool narrow = ub <= 65534;
+    if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
+    // compact layout (u16 only): 4-bit codes instead of the I plane, D rows only where they are read back.
+    // POA_CFG_FULL_PLANES (or POA_COMPACT=0) keeps all three planes, e.g. for poa_batch_fetch_planes.
+    bool compact = narrow && !(cfg && (cfg->flags & POA_CFG_FULL_PLANES));
+    if (const char* cv = getenv("POA_COMPACT")) { if (atoi(cv) == 0) compact = false; }
+    bool packed = true;  // packed-u16 arithmetic kernel for the compact layout (POA_PACKED=0: scalar u32 arithmetic)
+    if (const char* pv2 = getenv("POA_PACKED")) packed = atoi(pv2) != 0;
+    b->narrow = narrow;
+    b->compact = compact;
+    // 2-byte elements let twice the queries share the workspace; the exact replay needs the u32 plan
+    b->active_plan = (narrow && mode == POA_MODE_DENSE && !b->plan16_same) ? 1 : 0;
+    const poa_batch::Plan& PL = b->cur();
     std::vector<hipEvent_t> events;
-    if (!b->free_sets.empty()) { events = std::move(b->free_sets.back()); b->free_sets.pop_back(); }
-    else {
-        events.resize(2 + 3 * b->chunks.size());
+    const size_t n_events = 2 + 3 * PL.chunks.size();
+    for (size_t k = 0; k < b->free_sets.size(); ++k) {
+        if (b->free_sets[k].size() == n_events) {
+            events = std::move(b->free_sets[k]);
+            b->free_sets.erase(b->free_sets.begin() + (long)k);
+            break;
+        }
+    }
+    if (events.empty()) {
+        events.resize(n_events);
         for (auto& e : events) HIP_TRY(hipEventCreate(&e));
     }
     b->runs.push_back(events);
@@ -383,19 +427,6 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         b->ran = true;
         return POA_OK;
     }
-    // u16 planes whenever every finite score provably fits: a score is the cost of a path of at most
-    // rows + L edges, each costing at most max(x, o + e).  POA_PLANES=32 forces u32 (debug / A-B).
-    const uint64_t worst = ((uint64_t)fg.n + b->max_len + 2) * std::max<uint32_t>(costs->mismatch, (uint32_t)costs->gap_open + costs->gap_extend);
-    bool narrow = worst <= 65534;
-    if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
-    // compact layout (u16 only): 4-bit codes instead of the I plane, D rows only where they are read back.
-    // POA_CFG_FULL_PLANES (or POA_COMPACT=0) keeps all three planes, e.g. for poa_batch_fetch_planes.
-    bool compact = narrow && !(cfg && (cfg->flags & POA_CFG_FULL_PLANES));
-    if (const char* cv = getenv("POA_COMPACT")) { if (atoi(cv) == 0) compact = false; }
-    bool packed = true;  // packed-u16 arithmetic kernel for the compact layout (POA_PACKED=0: scalar u32 arithmetic)
-    if (const char* pv2 = getenv("POA_PACKED")) packed = atoi(pv2) != 0;
-    b->narrow = narrow;
-    b->compact = compact;
     uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round)
     if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
     bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
@@ -403,12 +434,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     int quads_override = 0;
     if (const char* ov = getenv("POA_FWD_QUADS")) quads_override = atoi(ov);  // tuning override
     size_t ev = 1;
-    for (const auto& ch : b->chunks) {
+    for (const auto& ch : PL.chunks) {
         TbParams tp;
         tp.rows = b->d_rows.p; tp.pred_rows = b->d_pred_rows.p; tp.n_rows = fg.n;
         tp.start_row = fg.start_row; tp.end_row = fg.end_row;
         tp.first_query = ch.first; tp.n_queries = ch.count;
-        tp.qseq = b->d_qseq.p; tp.qoff = b->d_qoff.p; tp.pitch = b->d_pitch.p; tp.plane_off = b->d_plane_off.p;
+        tp.qseq = b->d_qseq.p; tp.qoff = b->d_qoff.p; tp.pitch = b->d_pitch.p; tp.plane_off = PL.d_off.p;
         tp.planes = b->d_planes.p; tp.scratch_off = b->d_scratch_off.p; tp.scratch = b->d_scratch.p;
         tp.score = b->d_score.p; tp.flags = b->d_flags.p; tp.n_pairs = b->d_npairs.p;
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
@@ -417,7 +448,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         FwdParams fp;
         fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
         fp.first_query = ch.first; fp.n_queries = ch.count;
-        fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = b->d_plane_off.p;
+        fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = PL.d_off.p;
         fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
         fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
         const uint32_t blocks = (ch.count + 3) / 4;
@@ -433,8 +464,13 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
             if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
             if (compact && packed) {
-                if (quads == 1) hipLaunchKernelGGL((poa_forward_packed_kernel<1>), dim3(blocks), dim3(256), 0, stream, fp);
-                else hipLaunchKernelGGL((poa_forward_packed_kernel<2>), dim3(blocks), dim3(256), 0, stream, fp);
+                if (quads == 1) {
+                    if (fuse_tb) hipLaunchKernelGGL((poa_forward_packed_kernel<1, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                    else hipLaunchKernelGGL((poa_forward_packed_kernel<1, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                } else {
+                    if (fuse_tb) hipLaunchKernelGGL((poa_forward_packed_kernel<2, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                    else hipLaunchKernelGGL((poa_forward_packed_kernel<2, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                }
             } else if (compact) {
                 if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
                 else hipLaunchKernelGGL((poa_forward_kernel<2, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
@@ -450,7 +486,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
-        if (!fuse_tb || compact) {
+        if (!(fuse_tb && (!compact || packed))) {
             if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
@@ -462,7 +498,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             // exact replay of the reference's search on the (re-initialised, u32) planes of this chunk
             const uint32_t hybrid = mode == POA_MODE_HYBRID ? 1u : 0u;
             HIP_TRY(hipMemsetAsync(b->d_ex_status.p + ch.first, 0xFF, (size_t)ch.count * 4, stream));
-            hipLaunchKernelGGL(poa_fill_planes_kernel, dim3(64, ch.count), dim3(256), 0, stream, b->d_planes.p, b->d_plane_off.p,
+            hipLaunchKernelGGL(poa_fill_planes_kernel, dim3(64, ch.count), dim3(256), 0, stream, b->d_planes.p, PL.d_off.p,
                                b->d_pitch.p, fg.n, ch.first, hybrid, b->d_flags.p);
             HIP_TRY(hipGetLastError());
             if (fg.n_exit) {
@@ -474,7 +510,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             ep.G = ExactGraph{fg.n, fg.start_row, fg.end_row, b->d_ex_sym.p, b->d_succ_off.p, b->d_succ_rows.p, b->d_dist_min.p,
                               b->d_dist_max.p, b->d_exit_idx.p, fg.n_exit, b->d_nbm_off.p, b->d_nbm.p};
             ep.first_query = ch.first; ep.n_queries = ch.count; ep.hybrid = hybrid; ep.dense_flags = b->d_flags.p;
-            ep.qseq = b->d_qseq.p; ep.qoff = b->d_qoff.p; ep.pitch = b->d_pitch.p; ep.plane_off = b->d_plane_off.p;
+            ep.qseq = b->d_qseq.p; ep.qoff = b->d_qoff.p; ep.pitch = b->d_pitch.p; ep.plane_off = PL.d_off.p;
             ep.planes = b->d_planes.p;
             ep.reached = b->d_ex_reached.p; ep.rsum = b->d_ex_rsum.p; ep.wpn = b->ex_wpn; ep.swpn = b->ex_swpn;
             ep.head = b->d_ex_head.p; ep.n_prio = b->ex_n_prio; ep.pool = b->d_ex_pool.p; ep.pool_cap = b->ex_pool_cap;
@@ -603,7 +639,7 @@ int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t
     if (!b || !m || !i || !d) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: null argument");
     if (!b->ran || query >= b->n_queries) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: bad query / not run");
     if (b->compact) return fail(POA_ERR_UNSUPPORTED, "poa_batch_fetch_planes: the last run used the compact layout; run with POA_CFG_FULL_PLANES");
-    const auto& last = b->chunks.back();
+    const auto& last = b->cur().chunks.back();
     if (query < last.first || query >= last.first + last.count)
         return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: the query's planes were overwritten by a later chunk");
     HIP_TRY(hipSetDevice(b->device));
@@ -614,12 +650,12 @@ int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t
     uint32_t* dst[3] = {m, i, d};
     if (!b->narrow) {
         for (int k = 0; k < 3; ++k) {
-            const uint32_t* src = b->d_planes.p + b->h_plane_off[query] + k * RP;
+            const uint32_t* src = b->d_planes.p + b->cur().off[query] + k * RP;
             HIP_TRY(hipMemcpy2D(dst[k], (size_t)cols * 4, src, (size_t)pitch * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToHost));
         }
     } else {
         std::vector<uint16_t> tmp((size_t)rows * cols);
-        const uint16_t* base = reinterpret_cast<const uint16_t*>(b->d_planes.p) + b->h_plane_off[query];
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(b->d_planes.p) + b->cur().off[query];
         for (int k = 0; k < 3; ++k) {
             HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)cols * 2, base + k * RP, (size_t)pitch * 2, (size_t)cols * 2, rows, hipMemcpyDeviceToHost));
             for (size_t t = 0; t < tmp.size(); ++t) dst[k][t] = tmp[t] == 0xFFFFu ? 0xFFFFFFFFu : tmp[t];

@@ -55,8 +55,10 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus16(uint32_t t, uint32_t st
     return P;
 }
 
-template <int Q>
-__global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
+// FUSE_TB: the wave traces its own query right after its last row (the latency-bound walk then overlaps the other
+// waves' VALU-bound forward work instead of running as a separate launch; the traceback needs fewer registers).
+template <int Q, bool FUSE_TB>
+__global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, TbParams TP) {
     constexpr int K = 8;                 // columns per lane and quad
     constexpr int NP = 4 * Q;            // packed registers per row array (2 columns each)
     constexpr uint32_t QW = 64 * K;      // 512 columns per quad
@@ -267,6 +269,10 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P) {
             }
         }
         if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    if (FUSE_TB) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // my plane stores are complete before I read them back
+        traceback_wave<uint16_t, true>(TP, qi, lane);
     }
 }
 

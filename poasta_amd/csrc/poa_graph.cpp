@@ -139,6 +139,19 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
         if (m.flags & ROW_CHAIN) continue;
         for (uint32_t pe = 0; pe < m.pred_count; ++pe) g.rows[g.pred_rows[m.pred_begin + pe]].flags |= ROW_STORE_D;
     }
+    // shortest start -> end path, in real nodes (bounds the optimal score from above: see poa_batch_run_ex)
+    {
+        std::vector<uint32_t> dist(n, 0xFFFFFFFFu);
+        dist[g.start_row] = 0;
+        for (uint32_t r = 0; r < n; ++r) {
+            const RowMeta& m = g.rows[r];
+            for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+                const uint32_t d = dist[g.pred_rows[m.pred_begin + pe]];
+                if (d != 0xFFFFFFFFu && d + 1 < dist[r]) dist[r] = d + 1;
+            }
+        }
+        g.min_path_nodes = (dist[g.end_row] == 0xFFFFFFFFu || dist[g.end_row] == 0) ? 0 : dist[g.end_row] - 1;
+    }
     return POA_OK;
 }
 

@@ -41,6 +41,7 @@ struct FlatGraph {
     std::vector<uint32_t> pred_rows;     // predecessors as rows, trait order preserved
     uint32_t start_row = 0, end_row = 0;
     uint32_t max_indegree = 0;
+    uint32_t min_path_nodes = 0;         // real nodes on the shortest start -> end path
 
     // ---- exact-replay mode only: the reference's per-graph preprocessing --------------------
     // successors as rows, trait order preserved (DFA / expand_all iterate them in this order)

@@ -275,3 +275,26 @@ def test_world_size_2_gloo_shard_and_gather(oracle, tmp_path):
     for i in range(n_total):
         got = [tuple(x) for x in z["pairs"][int(z["off"][i]):int(z["off"][i + 1])].tolist()]
         assert got == oracle.batch_alignment(D, i)
+
+
+def test_mingap_with_pruning_can_be_suboptimal(oracle):
+    """Found while testing (parity unpinned: no reference fixture covers it, the reference cannot be built here):
+    restated literally, the reference's default search (min-gap heuristic + superbubble pruning) returns 501 where
+    Dijkstra order, or the same heuristic without pruning, or the dense recurrences return 500 — costs 8/3/1 on a
+    20 %-divergent read.  Query 9 differs through the offset-0 DFA quirk instead (dense flag START_QUIRK).  With
+    the CLI default costs 4/6/2 no such case appeared in 10 000 config-2 queries."""
+    g, (qseq, qoff) = W.scaled_linearish(420, 20, 10, 12, 400, p_sub=0.2, p_ins=0.05, p_del=0.05)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    oc = oracle.Costs(8, 3, 1)
+    D = og.dense_batch(qseq, qoff, oc, threads=4)
+    dij = og.astar_batch(qseq, qoff, oc, oracle.H_DIJKSTRA, False, threads=4)
+    dij_p = og.astar_batch(qseq, qoff, oc, oracle.H_DIJKSTRA, True, threads=4)
+    mg = og.astar_batch(qseq, qoff, oc, oracle.H_MINGAP, False, threads=4)
+    mg_p = og.astar_batch(qseq, qoff, oc, oracle.H_MINGAP, True, threads=4)
+    ok = [i for i in range(12) if dij["status"][i] == 0]
+    assert len(ok) == 10
+    for i in ok:
+        assert int(D["score"][i]) == int(dij["score"][i]) == int(dij_p["score"][i])
+    assert int(D["score"][4]) == 500 and int(mg["score"][4]) == 500 and int(mg_p["score"][4]) == 501
+    assert int(D["score"][9]) == 488 and int(mg["score"][9]) == 489 and int(D["flags"][9]) & 2
+    assert all(int(mg_p["score"][i]) == int(D["score"][i]) for i in ok if i not in (4, 9))

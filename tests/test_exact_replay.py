@@ -99,9 +99,9 @@ def test_replay_equals_oracle_search_cpu(oracle, harness):
 
 
 # ------------------------------------------------------------------------------------------------
-def _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(4, 6, 2), cfg_cls="AffineMinGapCost", pruning=True, mode="exact"):
+def _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(4, 6, 2), cfg_cls="AffineMinGapCost", pruning=True, mode="exact", allow_flags=0, queue_entries_per_cell=3.0):
     m, o, e = costs
-    al = engine.PoastaAligner(getattr(engine, cfg_cls)(engine.GapAffine(m, e, o)), mode=mode, queue_entries_per_cell=3.0)
+    al = engine.PoastaAligner(getattr(engine, cfg_cls)(engine.GapAffine(m, e, o)), mode=mode, queue_entries_per_cell=queue_entries_per_cell)
     qseq, qoff = pack_queries(qs)
     res = al.align_batch(g, qseq=qseq, qoff=qoff, pruning=pruning)
     og = oracle.OracleGraph.from_csr(g.as_dict())
@@ -112,9 +112,9 @@ def _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(4, 6, 2), cfg_cls="AffineM
         if A["status"][i] != 0:
             assert int(res.flags[i]) & 4, "reference panics: REF_PANIC expected"
             continue
+        assert int(res.flags[i]) & ~allow_flags == 0, "flags, query %d" % i
         assert int(res.score[i]) == int(A["score"][i]), "score, query %d" % i
         assert res.raw_alignment(i) == oracle.batch_alignment(A, i), "alignment, query %d" % i
-        assert int(res.flags[i]) == 0, "flags, query %d" % i
         n += 1
     return n, res
 
@@ -137,6 +137,20 @@ def test_gpu_exact_mode_is_bit_identical(engine, oracle):
     assert _gpu_exact_vs_astar(engine, oracle, poa.graph, poa.queries(10, length=0))[0] == 10
     pg = W.PangenomePOA(ref_len=400, n_hap=6, p_snp=0.02, p_indel=0.01, max_indel=6, seed=4)
     assert _gpu_exact_vs_astar(engine, oracle, pg.graph, pg.queries(8, length=150))[0] == 8
+
+
+@pytest.mark.gpu
+def test_gpu_exact_reproduces_suboptimal_pruned_search(engine, oracle):
+    """Costs 8/3/1, 20 % substitutions: the min-gap + pruning search returns 501 / 489 where the optimum is 500 / 488
+    (tests/test_cpu_side.py::test_mingap_with_pruning_can_be_suboptimal).  The replay must return what the search returns."""
+    g, (qseq, qoff) = W.scaled_linearish(420, 20, 10, 12, 400, p_sub=0.2, p_ins=0.05, p_del=0.05)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(12)]
+    # 0x10 = POA_FLAG_TRUNCATED: informational (the reference drops leading insertions from the alignment it returns)
+    n, res = _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(8, 3, 1), allow_flags=0x10)
+    assert n == 10 and int(res.score[4]) == 501 and int(res.score[9]) == 489
+    n, res = _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(8, 3, 1), cfg_cls="AffineDijkstra", pruning=False, allow_flags=0x10,
+                                 queue_entries_per_cell=12.0)  # Dijkstra order without pruning queues every cell several times
+    assert int(res.score[4]) == 500 and int(res.score[9]) == 488
 
 
 @pytest.mark.gpu

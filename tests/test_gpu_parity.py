@@ -50,10 +50,10 @@ def _check_against_dense(engine, oracle, g, qs, costs=(4, 6, 2), planes=False):
     return res, D
 
 
-def _check_against_astar(oracle, g, qs, res, costs=(4, 6, 2)):
+def _check_against_astar(oracle, g, qs, res, costs=(4, 6, 2), heuristic=None, pruning=True):
     og = oracle.OracleGraph.from_csr(g.as_dict())
     qseq, qoff = pack_queries(qs)
-    A = og.astar_batch(qseq, qoff, oracle.Costs(*costs), oracle.H_MINGAP, True, threads=4)
+    A = og.astar_batch(qseq, qoff, oracle.Costs(*costs), oracle.H_MINGAP if heuristic is None else heuristic, pruning, threads=4)
     n_certified = 0
     for i in range(len(qs)):
         if A["status"][i] != 0:
@@ -157,6 +157,54 @@ def test_medium_members_of_config4_and_config5(engine, oracle):
     qs = pg.queries(4, length=1500)                                     # 2 strips, Global against the whole graph
     res, _ = _check_against_dense(engine, oracle, pg.graph, qs)
     _check_against_astar(oracle, pg.graph, qs, res)
+
+
+def test_u16_planes_by_score_upper_bound(engine, oracle):
+    """Mismatch cost 255: the crude bound (rows + L + 2) * max(x, o + e) says u32, the bound on the OPTIMAL score
+    (insert the query + delete the shortest path) says u16 — cells only reachable through long mismatch runs
+    saturate to INF in u16, and nothing the result depends on may change."""
+    g, (qseq, qoff) = W.scaled_linearish(420, 20, 10, 12, 400, p_sub=0.2, p_ins=0.05, p_del=0.05)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(12)]
+    rng = np.random.default_rng(5)
+    qs.append(rng.choice(np.frombuffer(b"ACGT", np.uint8), 400))       # unrelated query: mismatch-heavy cells everywhere
+    # A* side: Dijkstra order without pruning (`AffineDijkstra` + `align_no_pruning`), which is optimal by construction;
+    # at this divergence the min-gap + pruning search can return a score 1 above the optimum of its own graph
+    # (tests/test_cpu_side.py::test_mingap_with_pruning_can_be_suboptimal) — the exact-replay mode reproduces that.
+    for costs in ((255, 3, 1), (200, 0, 1), (255, 6, 2)):
+        res, _ = _check_against_dense(engine, oracle, g, qs, costs=costs)
+        _check_against_astar(oracle, g, qs, res, costs=costs, heuristic=oracle.H_DIJKSTRA, pruning=False)
+    poa = W.LayeredPOA(n_layers=150, width=4, indeg=4, seed=7)
+    qs = poa.queries(6, length=140)
+    res, _ = _check_against_dense(engine, oracle, poa.graph, qs, costs=(255, 2, 1))
+    _check_against_astar(oracle, poa.graph, qs, res, costs=(255, 2, 1), heuristic=oracle.H_DIJKSTRA, pruning=False)
+
+
+def test_chunked_workspace_uses_both_plans(engine, oracle):
+    """A workspace too small for the batch: the u16 layouts pack twice the queries per chunk (plan 1), the exact
+    replay runs on the u32 plan (plan 0); results equal the unchunked run's either way."""
+    g, (qseq, qoff) = W.scaled_linearish(200, 10, 5, 24, 180)
+    costs = _costs(engine)
+    whole = engine.ResidentBatch(g, qseq, qoff)
+    whole.run(costs)
+    ref = whole.fetch()
+    per_query_u32 = 3 * (g.n) * 192 * 4
+    rb = engine.ResidentBatch(g, qseq, qoff, workspace_bytes=5 * per_query_u32)
+    rb.run(costs)
+    a = rb.fetch()
+    assert a.stats["n_chunks"] == 3                      # 10 queries per chunk in 2-byte elements
+    rb.run(costs, None, engine.make_config("exact"))
+    e = rb.fetch()
+    assert e.stats["n_chunks"] == 5                      # 5 per chunk in 4-byte elements
+    rb.run(costs, None, engine.make_config(full_planes=True))
+    f = rb.fetch()
+    assert np.array_equal(a.score, ref.score) and np.array_equal(f.score, ref.score) and np.array_equal(e.score, ref.score)
+    assert np.array_equal(a.flags, ref.flags) and np.array_equal(f.flags, ref.flags)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=4)
+    for i in range(24):
+        assert a.raw_alignment(i) == ref.raw_alignment(i) and f.raw_alignment(i) == ref.raw_alignment(i)
+        assert e.raw_alignment(i) == oracle.batch_alignment(A, i)
+    whole.close(); rb.close()
 
 
 def test_config2_sample_vs_astar(engine, oracle):
