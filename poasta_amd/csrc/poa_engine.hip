@@ -464,12 +464,22 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
             if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
             if (compact && packed) {
-                if (quads == 1) {
-                    if (fuse_tb) hipLaunchKernelGGL((poa_forward_packed_kernel<1, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
-                    else hipLaunchKernelGGL((poa_forward_packed_kernel<1, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                // queries longer than one strip: one workgroup per query, its strips pipelined over the waves (MW)
+                bool mw = max_pitch > 512 * quads;
+                if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
+                if (mw) {
+                    // narrow strips (more waves) until the chunk alone fills the chip
+                    if (!quads_override) quads = ((uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192) ? 2 : 1;
+                    const uint32_t strips = (max_pitch + 512 * quads - 1) / (512 * quads);
+                    const uint32_t waves = std::min<uint32_t>(strips, MW_MAX_WAVES);
+                    if (quads == 1) hipLaunchKernelGGL((poa_forward_packed_kernel<1, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
+                    else hipLaunchKernelGGL((poa_forward_packed_kernel<2, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
+                } else if (quads == 1) {
+                    if (fuse_tb) hipLaunchKernelGGL((poa_forward_packed_kernel<1, true, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                    else hipLaunchKernelGGL((poa_forward_packed_kernel<1, false, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
                 } else {
-                    if (fuse_tb) hipLaunchKernelGGL((poa_forward_packed_kernel<2, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
-                    else hipLaunchKernelGGL((poa_forward_packed_kernel<2, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                    if (fuse_tb) hipLaunchKernelGGL((poa_forward_packed_kernel<2, true, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
+                    else hipLaunchKernelGGL((poa_forward_packed_kernel<2, false, false>), dim3(blocks), dim3(256), 0, stream, fp, tp);
                 }
             } else if (compact) {
                 if (quads == 1) hipLaunchKernelGGL((poa_forward_kernel<1, uint16_t, false, true>), dim3(blocks), dim3(256), 0, stream, fp, tp);
@@ -486,7 +496,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
-        if (!(fuse_tb && (!compact || packed))) {
+        if (!(fuse_tb && (!compact || (packed && max_pitch <= 1024)))) {
             if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);

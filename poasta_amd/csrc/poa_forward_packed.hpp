@@ -57,15 +57,46 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus16(uint32_t t, uint32_t st
 
 // FUSE_TB: the wave traces its own query right after its last row (the latency-bound walk then overlaps the other
 // waves' VALU-bound forward work instead of running as a separate launch; the traceback needs fewer registers).
-template <int Q, bool FUSE_TB>
-__global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, TbParams TP) {
+//
+// MW ("multi-wave"): one WORKGROUP per query, wave w computes strip g*S + w (S = waves per block) — the strips of
+// a long query run as a software pipeline, wave w one or more rows behind wave w - 1.  What strip s needs from
+// strip s - 1 for row r is three scalars: the insertion-scan carry, I of its last column (for the code bit of my
+// first column) and M of its last column (the diagonal edge of the NEXT chain row).  They travel through an LDS
+// ring (MW_RING rows deep, with back-pressure) guarded by a per-wave progress counter; fences on that hand-over are
+// LDS-only, so no wave ever waits for its plane stores to be acknowledged.  Rows with several predecessors read the
+// edge column from the planes instead: the producer's begin-of-row fence of the same graph row has made its earlier
+// rows visible before it publishes that row.  Every wait is on a wave that is resident (same workgroup) and strictly
+// earlier in the chain, so the pipeline cannot deadlock; spins are bounded all the same.
+constexpr int MW_MAX_WAVES = 16;
+constexpr uint32_t MW_RING = 64;
+static_assert(MW_RING >= 2 * ROW_NEAR, "ring must hold the look-back window plus slack");
+
+__device__ __forceinline__ void mw_wait_gt(uint32_t* p, uint32_t v) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 27)) break;  // never reached in a correct pipeline; bounds a protocol bug to seconds
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int Q, bool FUSE_TB, bool MW>
+__global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(FwdParams P, TbParams TP) {
     constexpr int K = 8;                 // columns per lane and quad
     constexpr int NP = 4 * Q;            // packed registers per row array (2 columns each)
     constexpr uint32_t QW = 64 * K;      // 512 columns per quad
     constexpr uint32_t W = QW * Q;
     constexpr uint32_t I16 = 0xFFFFu, INF2 = 0xFFFFFFFFu;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t S = MW ? (blockDim.x >> 6) : 1u;  // strips in flight per query
+    __shared__ uint32_t mw_progress[MW ? MW_MAX_WAVES : 1];          // rows completed by wave w, over all its strips
+    __shared__ uint32_t mw_ring[MW ? MW_MAX_WAVES : 1][MW ? MW_RING : 1][4];  // {scan carry, I last col, M last col, -}
+    if (MW) {
+        if (threadIdx.x < MW_MAX_WAVES) mw_progress[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const uint32_t wq = MW ? blockIdx.x : (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
     const uint32_t qi = P.first_query + wq;
     const uint64_t qbeg = P.qoff[qi];
@@ -89,7 +120,21 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
     for (int i = 0; i < 4; ++i) off2[i] = (2 * i * e) | ((2 * i + 1) * e << 16);
     const uint32_t inf2 = INF2;
 
-    for (uint32_t s = 0; s < n_strips; ++s) {
+    const uint32_t n_groups = (n_strips + S - 1) / S;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t s = g * S + (MW ? wave : 0u);
+        if (MW && s >= n_strips) break;
+        const bool from_ring = MW && wave > 0;                          // strip s - 1 is being computed by wave - 1 right now
+        const bool from_global = s > 0 && !from_ring;                   // ... or was finished earlier (carry array + planes)
+        const bool to_ring = MW && wave + 1 < S && s + 1 < n_strips;
+        const bool to_global = s + 1 < n_strips && !to_ring;
+        const uint32_t prog_base = g * P.n_rows;
+        uint32_t m_edge_prev = I16;                                     // from_ring: M[r-1][sbase-1]
+        if (MW && from_global) {
+            // wave 0 of a later group: the last wave must have finished (and released) the whole previous group
+            mw_wait_gt(&mw_progress[S - 1], prog_base - 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         const uint32_t sbase = s * W;
         bool act[Q];
         uint32_t qP[NP];   // my query symbols, 16 bits each (0 past the end: never a symbol)
@@ -116,10 +161,17 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
             const uint32_t sym2 = sym | (sym << 16);
             const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
             uint32_t PMl[Q];  // hi half = min over predecessors of M[p][my first column - 1]
+            uint32_t in_cq = I16, in_ilast = I16, in_mlast = I16;
+            if (from_ring) {
+                mw_wait_gt(&mw_progress[wave - 1], prog_base + r);
+                const uint32_t* slot = mw_ring[wave - 1][(prog_base + r) % MW_RING];
+                in_cq = slot[0]; in_ilast = slot[1]; in_mlast = slot[2];
+            }
             // the row itself, given the predecessor minima PM / PD; the chain path passes the previous row's
             // registers themselves (no copies)
             auto row_body = [&](const uint32_t (&PM)[NP], const uint32_t (&PD)[NP]) {
                 uint32_t Mc[NP], Ic[NP], Dc[NP], Hc[NP], PDe[NP];
+                uint32_t cq_out = I16;  // scan carry leaving this strip
 #pragma unroll
                 for (int p = 0; p < NP; ++p) PDe[p] = pk_add_sat(PD[p], e2);
                 if (meta.flags & ROW_END) {
@@ -168,7 +220,7 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
 #pragma unroll
                         for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = iloc[pp];
                     }
-                    uint32_t cq = (s > 0) ? carry[2 * r] : I16;
+                    uint32_t cq = from_ring ? in_cq : (from_global ? carry[2 * r] : I16);
 #pragma unroll
                     for (int m = 0; m < Q; ++m) {
                         const uint32_t Pm = wave_scan_min_plus16(Tq[m], step, w15, w31);
@@ -180,7 +232,8 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
 #pragma unroll
                         for (int pp = 0; pp < 4; ++pp) Ic[4 * m + pp] = pk_min(Ic[4 * m + pp], pk_add_sat(cin2, off2[pp]));
                     }
-                    if (n_strips > 1 && lane == 0) carry[2 * r] = cq;
+                    if (to_global && lane == 0) carry[2 * r] = cq;
+                    cq_out = cq;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) Mc[p] = pk_min(Hc[p], Ic[p]);
                 }
@@ -190,7 +243,8 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
                 uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
                 const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
                 uint32_t edge_i = inf2;
-                if (s > 0) edge_i = carry[2 * r + 1] << 16;
+                if (from_ring) edge_i = in_ilast << 16;
+                else if (from_global) edge_i = carry[2 * r + 1] << 16;
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
                     uint32_t i_prev = pk_wave_shr1(Ic[4 * m + 3], edge_i);
@@ -215,14 +269,30 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
                         codes[m * (QW / 8)] = word;
                     }
                 }
-                if (n_strips > 1 && lane == 63) carry[2 * r + 1] = Ic[NP - 1] >> 16;
+                if (to_global && lane == 63) carry[2 * r + 1] = Ic[NP - 1] >> 16;
+                if (MW) {
+                    if (to_ring) {
+                        // back-pressure: the slot I am about to overwrite was read MW_RING rows ago
+                        // (the consumer may still look ROW_NEAR rows back from the row it is working on)
+                        if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING);
+                        if (lane == 63) {
+                            uint32_t* slot = mw_ring[wave][(prog_base + r) % MW_RING];
+                            slot[0] = cq_out; slot[1] = Ic[NP - 1] >> 16; slot[2] = Mc[NP - 1] >> 16;
+                        }
+                    }
+                    // the last row of a strip whose successor reads the carry ARRAY must also release my global stores
+                    if (to_global && r + 1 == P.n_rows) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    if (lane == 0) __hip_atomic_store(&mw_progress[wave], prog_base + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { Mprev[p] = Mc[p]; Dprev[p] = Dc[p]; }
             };
 
             if (meta.flags & ROW_CHAIN) {
                 uint32_t edge = inf2;
-                if (s > 0) edge = (uint32_t)Mp[(uint64_t)(r - 1) * pitch + sbase - 1] << 16;
+                if (from_ring) edge = m_edge_prev << 16;
+                else if (from_global) edge = (uint32_t)Mp[(uint64_t)(r - 1) * pitch + sbase - 1] << 16;
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
                     PMl[m] = pk_wave_shr1(Mprev[4 * m + 3], edge);
@@ -235,7 +305,11 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
                 for (int p = 0; p < NP; ++p) { PM[p] = inf2; PD[p] = inf2; }
 #pragma unroll
                 for (int m = 0; m < Q; ++m) PMl[m] = inf2;
-                if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                // I read back rows this wave stored itself: wavefront scope orders that.  The column left of my strip
+                // was stored by wave - 1 (MW): near rows come through the LDS ring, a far one needs workgroup scope —
+                // on the same graph row of BOTH waves, so that the producer has released before it published the row.
+                if (MW && (meta.flags & ROW_FAR_PRED)) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                else if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
                     const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
                     const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
@@ -256,7 +330,8 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
                         }
                     }
                     uint32_t edge = inf2;
-                    if (s > 0) edge = (uint32_t)Mp[(uint64_t)pr * pitch + sbase - 1] << 16;
+                    if (from_ring && r - pr <= ROW_NEAR) edge = mw_ring[wave - 1][(prog_base + pr) % MW_RING][2] << 16;
+                    else if (s > 0) edge = (uint32_t)Mp[(uint64_t)pr * pitch + sbase - 1] << 16;
 #pragma unroll
                     for (int m = 0; m < Q; ++m) {
                         PMl[m] = pk_min(PMl[m], pk_wave_shr1(tm[4 * m + 3], edge));
@@ -267,6 +342,7 @@ __global__ __launch_bounds__(256) void poa_forward_packed_kernel(FwdParams P, Tb
                 }
                 row_body(PM, PD);
             }
+            m_edge_prev = in_mlast;
         }
         if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }

@@ -116,6 +116,8 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
             g.pred_rows.push_back(pr);
         }
         m.flags = 0;
+        for (uint32_t pe = 0; pe < m.pred_count; ++pe)
+            if (r - g.pred_rows[m.pred_begin + pe] > ROW_NEAR) m.flags |= ROW_FAR_PRED;
         if (m.pred_count == 1 && g.pred_rows[m.pred_begin] + 1 == r) m.flags |= ROW_CHAIN;
         if (v == start) m.flags |= ROW_START;
         if (v == end) m.flags |= ROW_END;

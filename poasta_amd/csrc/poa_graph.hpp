@@ -18,7 +18,9 @@ enum : uint8_t {
     ROW_OPENI_NEVER = 8,   // no successors at all (only the end row)
     ROW_CHAIN = 16,        // exactly one predecessor and it is the previous row
     ROW_STORE_D = 32,      // some successor reads this row's D from memory (it is not a chain row right below): keep the D row
+    ROW_FAR_PRED = 64,     // some predecessor lies more than ROW_NEAR rows back (multi-wave kernel: beyond the hand-over ring)
 };
+constexpr uint32_t ROW_NEAR = 32;
 
 struct RowMeta {  // 16 bytes, one per row
     uint32_t node;        // node index in the host graph (rpos of AlignedPair)

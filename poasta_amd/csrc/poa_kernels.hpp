@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                 for (int m = 0; m < Q; ++m) PMl[m] = INF;
                 // rows written earlier by this wave are re-read below by other lanes of the wave:
                 // drain the stores first (write-through L1; the lines are then fetched from L2).
-                if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // I read back rows this wave stored
                 for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
                     const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
                     const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;

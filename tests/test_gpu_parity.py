@@ -132,6 +132,20 @@ def test_multi_strip_long_queries(engine, oracle):
     rb_res, _ = _check_against_dense(engine, oracle, g, qs[4:6], planes=True)
 
 
+def test_multi_wave_pipeline(engine, oracle):
+    """Long queries run one workgroup per query with the strips pipelined over its waves: mixed lengths in one launch
+    (waves beyond a query's last strip exit early), more strips than waves (a second group through the carry array),
+    and a bubble-rich graph where every row reads several predecessors from the planes."""
+    g, (qseq, qoff) = W.scaled_linearish(260, 12, 6, 3, 9000, p_sub=0.03, p_ins=0.02, p_del=0.02)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(3)]
+    qs = [qs[0], qs[1][:700], qs[2][:3000], qs[1][:8191], qs[2][:8192], qs[0][:1500]]   # 18, 2, 6, 16, 17 (512-col) strips
+    res, _ = _check_against_dense(engine, oracle, g, qs)
+    poa = W.LayeredPOA(n_layers=120, width=4, indeg=4, seed=9)
+    qs = poa.queries(5, length=2600)
+    res, _ = _check_against_dense(engine, oracle, poa.graph, qs)
+    _check_against_astar(oracle, poa.graph, qs, res)
+
+
 def test_deep_bubbles(engine, oracle):
     poa = W.LayeredPOA(n_layers=60, width=4, indeg=4, seed=5)
     qs = poa.queries(10, length=0)
