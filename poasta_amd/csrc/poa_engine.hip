@@ -489,14 +489,26 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         } else {
             uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);  // 256 columns per quad (4 x u32 per lane)
             if (quads_override == 1 || quads_override == 2 || quads_override == 4) quads = (uint32_t)quads_override;
-            if (quads == 1) LAUNCH_FWD(1, uint32_t);
+            bool mw = max_pitch > 1024;  // longer than the widest strip: pipeline the strips over the waves of a workgroup
+            if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
+            if (mw) {
+                // 512-column strips (up to 16 waves per query) until the chunk alone fills the chip, else 1024 (up to 10)
+                const bool wide = quads_override == 4 || (!quads_override && (uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192);
+                if (wide) {
+                    const uint32_t waves = std::min<uint32_t>((max_pitch + 1023) / 1024, 10);
+                    hipLaunchKernelGGL((poa_forward_kernel<4, uint32_t, false, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
+                } else {
+                    const uint32_t waves = std::min<uint32_t>((max_pitch + 511) / 512, MW_MAX_WAVES);
+                    hipLaunchKernelGGL((poa_forward_kernel<2, uint32_t, false, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
+                }
+            } else if (quads == 1) LAUNCH_FWD(1, uint32_t);
             else if (quads == 2) LAUNCH_FWD(2, uint32_t);
             else LAUNCH_FWD(4, uint32_t);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
-        if (!(fuse_tb && (!compact || (packed && max_pitch <= 1024)))) {
+        if (!(fuse_tb && max_pitch <= 1024 && (!compact || packed))) {
             if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);

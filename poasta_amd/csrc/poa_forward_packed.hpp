@@ -67,19 +67,6 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus16(uint32_t t, uint32_t st
 // edge column from the planes instead: the producer's begin-of-row fence of the same graph row has made its earlier
 // rows visible before it publishes that row.  Every wait is on a wave that is resident (same workgroup) and strictly
 // earlier in the chain, so the pipeline cannot deadlock; spins are bounded all the same.
-constexpr int MW_MAX_WAVES = 16;
-constexpr uint32_t MW_RING = 64;
-static_assert(MW_RING >= 2 * ROW_NEAR, "ring must hold the look-back window plus slack");
-
-__device__ __forceinline__ void mw_wait_gt(uint32_t* p, uint32_t v) {
-    uint32_t spins = 0;
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 27)) break;  // never reached in a correct pipeline; bounds a protocol bug to seconds
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 template <int Q, bool FUSE_TB, bool MW>
 __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(FwdParams P, TbParams TP) {
     constexpr int K = 8;                 // columns per lane and quad

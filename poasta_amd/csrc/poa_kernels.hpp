@@ -435,8 +435,22 @@ __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
 // place:  bit0 I==M   bit1 I[j]==I[j-1]+e   bit2 D==M   bit3 D==PD+e; within a dword the
 // nibble of column k (0..7) sits at position (k >> 1) + 4 * (k & 1).  They are exactly the predicates the
 // traceback evaluates on I and (for chain rows) D; see traceback_wave.
-template <int Q, typename T, bool FUSE_TB, bool COMPACT>
-__global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(FwdParams P, TbParams TP) {
+// MW: one workgroup per query, its strips pipelined over the waves — described at poa_forward_packed_kernel.
+constexpr int MW_MAX_WAVES = 16;
+constexpr uint32_t MW_RING = 64;
+static_assert(MW_RING >= 2 * ROW_NEAR, "ring must hold the look-back window plus slack");
+
+__device__ __forceinline__ void mw_wait_gt(uint32_t* p, uint32_t v) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 27)) break;  // never reached in a correct pipeline; bounds a protocol bug to seconds
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int Q, typename T, bool FUSE_TB, bool COMPACT, bool MW = false>
+__global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES) void poa_forward_kernel(FwdParams P, TbParams TP) {
     static_assert(!COMPACT || PlaneIO<T>::K == 8, "compact codes assume 8 columns per lane and quad");
     using IO = PlaneIO<T>;
     constexpr int K = IO::K;
@@ -444,7 +458,15 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
     constexpr uint32_t QW = 64 * K;  // columns per quad
     constexpr uint32_t W = QW * Q;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t S = MW ? (blockDim.x >> 6) : 1u;  // strips in flight per query
+    __shared__ uint32_t mw_progress[MW ? MW_MAX_WAVES : 1];
+    __shared__ uint32_t mw_ring[MW ? MW_MAX_WAVES : 1][MW ? MW_RING : 1][4];  // {scan carry, I last col, M last col, -}
+    if (MW) {
+        if (threadIdx.x < MW_MAX_WAVES) mw_progress[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const uint32_t wq = MW ? blockIdx.x : (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
     if (wq >= P.n_queries) return;
     const uint32_t qi = P.first_query + wq;
     const uint64_t qbeg = P.qoff[qi];
@@ -463,7 +485,20 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
     const uint32_t w31 = (lane - 31u) * step;         // only used by lanes >= 32
     const uint32_t lane_off = K * lane * e;           // cost of extending an insertion to my first column of a quad
 
-    for (uint32_t s = 0; s < n_strips; ++s) {
+    const uint32_t n_groups = (n_strips + S - 1) / S;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t s = g * S + (MW ? wave : 0u);
+        if (MW && s >= n_strips) break;
+        const bool from_ring = MW && wave > 0;                          // strip s - 1 is being computed by wave - 1 right now
+        const bool from_global = s > 0 && !from_ring;                   // ... or was finished earlier (carry array + planes)
+        const bool to_ring = MW && wave + 1 < S && s + 1 < n_strips;
+        const bool to_global = s + 1 < n_strips && !to_ring;
+        const uint32_t prog_base = g * P.n_rows;
+        uint32_t m_edge_prev = INF;                                     // from_ring: M[r-1][sbase-1]
+        if (MW && from_global) {
+            mw_wait_gt(&mw_progress[S - 1], prog_base - 1);             // the whole previous group is done and released
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         const uint32_t sbase = s * W;
         bool act[Q];            // my K columns of quad m lie inside the plane row
         uint32_t qcp[C / 4];    // my query symbols, one per byte; 0 (never a symbol) past the end
@@ -495,12 +530,19 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
             const uint32_t sym = meta.sym;
             const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
             uint32_t PM[C], PD[C], PMl[Q];
+            uint32_t in_cq = INF, in_ilast = INF, in_mlast = INF, cq_out = INF;
+            if (from_ring) {
+                mw_wait_gt(&mw_progress[wave - 1], prog_base + r);
+                const uint32_t* slot = mw_ring[wave - 1][(prog_base + r) % MW_RING];
+                in_cq = slot[0]; in_ilast = slot[1]; in_mlast = slot[2];
+            }
 
             const bool chain = (meta.flags & ROW_CHAIN) != 0;
             if (chain) {
                 // fast path: the only predecessor is the previous row, still in registers
                 uint32_t edge = INF;
-                if (s > 0) edge = IO::get(Mp + (uint64_t)(r - 1) * pitch + sbase - 1);  // uniform address
+                if (from_ring) edge = m_edge_prev;
+                else if (from_global) edge = IO::get(Mp + (uint64_t)(r - 1) * pitch + sbase - 1);  // uniform address
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
                     PMl[m] = wave_shr1(Mprev[K * m + K - 1], edge);
@@ -515,7 +557,10 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                 for (int m = 0; m < Q; ++m) PMl[m] = INF;
                 // rows written earlier by this wave are re-read below by other lanes of the wave:
                 // drain the stores first (write-through L1; the lines are then fetched from L2).
-                if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // I read back rows this wave stored
+                // I read back rows this wave stored itself (wavefront scope); MW: a far predecessor's edge column comes
+                // from the planes of wave - 1, released by its fence on this same graph row
+                if (MW && (meta.flags & ROW_FAR_PRED)) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                else if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
                     const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
                     const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
@@ -538,7 +583,8 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                         }
                     }
                     uint32_t edge = INF;
-                    if (s > 0) edge = IO::get(Mp + (uint64_t)pr * pitch + sbase - 1);
+                    if (from_ring && r - pr <= ROW_NEAR) edge = mw_ring[wave - 1][(prog_base + pr) % MW_RING][2];
+                    else if (s > 0) edge = IO::get(Mp + (uint64_t)pr * pitch + sbase - 1);
 #pragma unroll
                     for (int m = 0; m < Q; ++m) {
                         PMl[m] = umin(PMl[m], wave_shr1(tm[K * m + K - 1], edge));
@@ -582,7 +628,7 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                     Tq[m] = t;  // leaves my last column of quad m (carry-in INF)
                 }
                 // cross-lane: independent scans per quad, then a uniform carry chain over the quads
-                uint32_t cq = (s > 0) ? carry[2 * r] : INF;  // insertion value entering column sbase
+                uint32_t cq = from_ring ? in_cq : (from_global ? carry[2 * r] : INF);  // insertion value entering column sbase
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
                     const uint32_t Pm = wave_scan_min_plus(Tq[m], step, w15, w31);
@@ -594,7 +640,8 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
 #pragma unroll
                     for (int k = 1; k < K; ++k) Ic[K * m + k] = umin(Ic[K * m + k], sat_add(cin, (uint32_t)k * e));
                 }
-                if (n_strips > 1 && lane == 0) carry[2 * r] = cq;  // I[r][(s+1)*W]
+                if (to_global && lane == 0) carry[2 * r] = cq;  // I[r][(s+1)*W]
+                cq_out = cq;
 #pragma unroll
                 for (int k = 0; k < C; ++k) Mc[k] = umin(H[k], Ic[k]);
             }
@@ -612,7 +659,8 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                 uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
                 const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
                 uint32_t edge_i = INF;  // I of the column left of my first column of the quad
-                if (s > 0) edge_i = carry[2 * r + 1];
+                if (from_ring) edge_i = in_ilast;
+                else if (from_global) edge_i = carry[2 * r + 1];
                 // (for s > 0 the value was written by lane 63 at the end of the previous strip of this row)
 #pragma unroll
                 for (int m = 0; m < Q; ++m) {
@@ -635,8 +683,22 @@ __global__ __launch_bounds__(256, POA_FWD_MIN_WAVES) void poa_forward_kernel(Fwd
                         codes[m * (QW / 8)] = code;
                     }
                 }
-                if (n_strips > 1 && lane == 63) carry[2 * r + 1] = Ic[C - 1];  // I[r][(s+1)*W - 1]
+                if (to_global && lane == 63) carry[2 * r + 1] = Ic[C - 1];  // I[r][(s+1)*W - 1]
             }
+            if (MW) {
+                if (to_ring) {
+                    // back-pressure: the consumer may still look ROW_NEAR rows back from the row it is working on
+                    if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING);
+                    if (lane == 63) {
+                        uint32_t* slot = mw_ring[wave][(prog_base + r) % MW_RING];
+                        slot[0] = cq_out; slot[1] = Ic[C - 1]; slot[2] = Mc[C - 1];
+                    }
+                }
+                if (to_global && r + 1 == P.n_rows) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&mw_progress[wave], prog_base + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            m_edge_prev = in_mlast;
 #pragma unroll
             for (int k = 0; k < C; ++k) { Mprev[k] = Mc[k]; Dprev[k] = Dc[k]; }
         }
