@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpoasta_amd.so")
+LIB_PATH = os.environ.get("POA_LIB_PATH") or os.path.join(_HERE, "libpoasta_amd.so")  # override: A/B runs of two builds
 CSRC = os.path.join(_HERE, "csrc")
 
 POA_OK = 0

@@ -347,43 +347,54 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         }
     }
     bool reached_start = done;  // nothing to truncate in the special cases
+    uint32_t d_run = 0;         // deletion steps taken in the current run (wave-uniform)
     while (!done) {
+        // speculation: in Match state lane i assumes i (mis)matches into the previous row came before it, in Deletion
+        // state i deletion-extensions into the previous row (long deletion runs: a read against a much longer graph)
         uint32_t depth = 1;
         if (cst == 0) {
             depth = P.spec_depth;
             if (crow + 1 < depth) depth = crow + 1;
             if (cj + 1 < depth) depth = cj + 1;
+        } else if (cst == 1) {
+            // ramp up with the length of the run so far: most deletions are one or two rows long
+            depth = d_run < P.spec_depth ? (d_run ? d_run : 1u) : P.spec_depth;
+            if (crow + 1 < depth) depth = crow + 1;
         }
+        if (cst != 1) d_run = 0;
         const bool active = lane < depth;
-        const uint32_t my_row = crow - lane, my_j = cj - lane;
+        const uint32_t my_row = crow - lane, my_j = (cst == 0) ? cj - lane : cj;
+        const uint32_t my_gcs = (cst == 1) ? gcs - lane * c.e : gcs;
         TbStep bt{0, 0, 0, false, 0};
         uint32_t nc = 0;
         bool bad = false, pn = false;
-        if (active) bt = tb_step<T, COMPACT>(c, my_row, my_j, cst, gcs, nc, bad, pn);
+        if (active) bt = tb_step<T, COMPACT>(c, my_row, my_j, cst, my_gcs, nc, bad, pn);
         const bool amb = active && bt.found && (nc != 1 || bad);
         const bool quirk = active && bt.found && bt.st == 0 && bt.j == 0 && bt.row != c.start_row && cst != 1 &&
                            (uint32_t)c.rows[bt.row].sym == (uint32_t)c.q[0];
         // a "regular" step: (mis)match into exactly the cell the next lane speculated on, not yet at start
-        const bool regular = active && cst == 0 && bt.found && bt.st == 0 && bt.row + 1 == my_row &&
-                             bt.j + 1 == my_j && bt.row != c.start_row;
+        const bool regular = active && bt.found && bt.row + 1 == my_row && bt.row != c.start_row &&
+                             ((cst == 0 && bt.st == 0 && bt.j + 1 == my_j) || (cst == 1 && bt.st == 1 && bt.j == my_j));
         const uint64_t rb = __ballot(regular);
         const uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
         const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
         if (__ballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
         if (__ballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
         if (__ballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
-        if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, my_j - 1);
+        if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, cst == 0 ? my_j - 1 : POA_NONE);
         cnt += p;
         if (p == depth) {
-            // every speculated step was regular: continue below the last one
-            crow -= depth; cj -= depth;  // state stays Match
+            // every speculated step was regular: continue below the last one, in the same state
+            crow -= depth;
+            if (cst == 0) cj -= depth;
+            else { gcs -= depth * c.e; d_run += depth; }
             continue;
         }
         // lane p deviates: replay the sequential rule with its results
         const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
         const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_pn = bc(pn ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
         const uint32_t d_cs = bc(bt.cs, p);
-        const uint32_t cur_row = crow - p, cur_j = cj - p, cur_st = (p == 0) ? cst : 0u;
+        const uint32_t cur_row = crow - p, cur_j = (cst == 0) ? cj - p : cj, cur_st = cst;  // speculation keeps the state
         if (d_pn) flags |= POA_FLAG_REF_PANIC;
         if (!d_found) break;
         if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
@@ -402,6 +413,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         if (d_quirk) flags |= POA_FLAG_START_QUIRK;
         if (d_row == c.start_row) { reached_start = true; break; }
         if (cur_st == 1 && d_st == 1) gcs = d_cs - c.e;  // D -> D: one more extension
+        if (cur_st == 1) d_run += p + 1;
         crow = d_row; cj = d_j; cst = d_st;
     }
     if (!reached_start) flags |= POA_FLAG_TRUNCATED;
