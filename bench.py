@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="queries timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on ONE GPU: every rank uses cuda:0 and the gather runs over gloo (not a measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -52,13 +54,19 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse else dev  # where the tensors of the collectives live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from poasta_amd import aligner, workloads
 
@@ -96,7 +104,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     st = batch.stats()  # HIP events recorded on `stream` around every kernel of the timed steps
-    elapsed_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    elapsed_t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)
     elapsed_max = float(elapsed_t.item())
@@ -109,7 +117,7 @@ def main():
     if dist is not None and not args.no_gather:
         ptrs = batch.device_results()
         rec = torch.stack([torch.from_numpy(res.score.astype(np.int64)), torch.from_numpy(res.flags.astype(np.int64)),
-                           torch.from_numpy((res.pair_off[1:] - res.pair_off[:-1]).astype(np.int64))], dim=1).to(dev)
+                           torch.from_numpy((res.pair_off[1:] - res.pair_off[:-1]).astype(np.int64))], dim=1).to(cdev)
         out = [torch.empty_like(rec) for _ in range(world)]
         torch.cuda.synchronize()
         g0 = time.perf_counter()
