@@ -148,6 +148,12 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if os.environ.get("POA_PLANES") == "32":
+            kernel_name = "poa_forward_kernel<4, unsigned int>"
+        elif os.environ.get("POA_COMPACT") == "0" or os.environ.get("POA_PACKED") == "0":
+            kernel_name = "poa_forward_kernel<2, unsigned short>"
+        else:
+            kernel_name = "poa_forward_packed_kernel<2>"
         line = {
             "metric": "Gcells/sec (aligned bases/sec in config), gap-affine POA alignment, 1k-node POA x 10k x 1 kbp queries per GPU",
             "value": round(gcells, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,7 +170,7 @@ def main():
                        "workload_gen_s": round(t_gen, 2), "plane_chunks": st["n_chunks"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "poa_forward_kernel<Q>", "avg_launch_ms": round(avg_launch_ms, 3),
+                         "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
                          "launches_timed": launches, "cells_per_launch": int(cells_per_launch),
                          "alg_bytes_per_cell": ALG_BYTES_PER_CELL,
                          "note": "B_alg is fixed at 12 B/cell (the reference's three u32 score planes, SURVEY.md 8d); the "
