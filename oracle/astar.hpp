@@ -182,6 +182,14 @@ struct AstarResult {  // astar.rs:81-90
     size_t num_queued = 0, num_visited = 0, num_pruned = 0;
 };
 
+// AlignmentType, scoring/mod.rs:50-62 (std::ops::Bound<usize> per end)
+enum BoundKind : uint32_t { BOUND_UNBOUNDED = 0, BOUND_INCLUDED = 1, BOUND_EXCLUDED = 2 };
+struct Bound { uint32_t kind = BOUND_UNBOUNDED; uint64_t v = 0; };
+struct AlnType {
+    bool ends_free = false;  // false: Global
+    Bound qry_free_begin, qry_free_end, graph_free_begin, graph_free_end;
+};
+
 class Aligner {
 public:
     const Graph& g;
@@ -189,6 +197,7 @@ public:
     Costs costs;
     Heuristic heuristic;
     bool enable_pruning;
+    AlnType aln_type;  // Global unless set
     std::vector<uint32_t> ranks;
 
     // per-alignment state (AffineAstarData, gap_affine.rs:702-712)
@@ -322,9 +331,54 @@ public:
         return false;
     }
 
-    // gap_affine.rs:185-194 (Global)
+    // dist_to_end, gap_affine.rs:91-119: BFS over successors, nodes at distance >= max are not expanded
+    bool dist_to_end(uint32_t from, size_t max, size_t& out) const {
+        std::vector<std::pair<uint32_t, size_t>> queue;
+        std::vector<uint8_t> seen(g.node_count_with_start_and_end(), 0);
+        queue.push_back({from, 0});
+        seen[from] = 1;
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const auto [n, dist] = queue[head];
+            if (n == g.end) { out = dist; return true; }
+            if (dist >= max) continue;
+            for (uint32_t sn : g.succ[n])
+                if (!seen[sn]) { seen[sn] = 1; queue.push_back({sn, dist + 1}); }
+        }
+        return false;
+    }
+
+    // gap_affine.rs:136-183
+    std::vector<AlnNode> initial_states() const {
+        std::vector<AlnNode> init;
+        if (!aln_type.ends_free) { init.push_back({g.start, 0}); return init; }
+        if (aln_type.graph_free_begin.kind == BOUND_UNBOUNDED) {
+            // every real node at offset 0, pushed in REVERSE index order ("queue processes in LIFO order")
+            const uint32_t n = (uint32_t)g.node_count_with_start_and_end();
+            for (uint32_t v = 0; v < n; ++v)
+                if (v != g.start && v != g.end) init.push_back({v, 0});
+            std::reverse(init.begin(), init.end());
+        } else {
+            init.push_back({g.start, 0});
+        }
+        if (init.empty()) init.push_back({g.start, 0});
+        return init;
+    }
+
+    // gap_affine.rs:185-248
     bool is_end(const AlnNode& a, AlignState st) const {
-        return st == ST_M && a.node == g.end && (size_t)a.offset == seq_len;
+        if (!aln_type.ends_free) return st == ST_M && a.node == g.end && (size_t)a.offset == seq_len;
+        bool q_ok;
+        const Bound& qe = aln_type.qry_free_end;
+        if (qe.kind == BOUND_UNBOUNDED) q_ok = a.offset > 0 || seq_len == 0;   // sic: ANY consumed prefix may end
+        else if (qe.kind == BOUND_INCLUDED) q_ok = seq_len - (size_t)a.offset <= qe.v;
+        else q_ok = seq_len - (size_t)a.offset < qe.v;
+        bool g_ok;
+        const Bound& ge = aln_type.graph_free_end;
+        size_t d = 0;
+        if (ge.kind == BOUND_UNBOUNDED) g_ok = true;
+        else if (ge.kind == BOUND_INCLUDED) g_ok = dist_to_end(a.node, ge.v, d) && d <= ge.v;
+        else g_ok = dist_to_end(a.node, ge.v ? ge.v - 1 : 0, d) && d < ge.v;
+        return st == ST_M && q_ok && g_ok;
     }
 
     struct Ctx {
@@ -532,10 +586,11 @@ public:
         touched_exits.clear();
 
         Ctx c;
-        AlnNode init{g.start, 0};  // gap_affine.rs:141
-        c.queue.queue({0, init, ST_M}, 0 + h(init, ST_M));
-        visited.set_score(init, ST_M, 0);
-        c.result.num_queued += 1;
+        for (const AlnNode& init : initial_states()) {  // astar.rs:133-139
+            c.queue.queue({0, init, ST_M}, 0 + h(init, ST_M));
+            visited.set_score(init, ST_M, 0);
+            c.result.num_queued += 1;
+        }
 
         Score end_score; AlnNode end_node;
         for (;;) {

@@ -28,9 +28,22 @@ struct GraphHandle {
 thread_local std::string g_last_error;
 }  // namespace
 
+// Alignment span for every Aligner constructed afterwards (test-side knob; default Global).
+static AlnType g_aln_type;
+static void apply_aln_type(Aligner& a) { a.aln_type = g_aln_type; }
+
 extern "C" {
 
 const char* oracle_last_error() { return g_last_error.c_str(); }
+
+// spec: {ends_free, then (kind, value) for qry_free_begin, qry_free_end, graph_free_begin, graph_free_end}
+void oracle_set_alignment_type(const uint64_t* spec) {
+    g_aln_type = AlnType{};
+    if (!spec || !spec[0]) return;
+    g_aln_type.ends_free = true;
+    Bound* b[4] = {&g_aln_type.qry_free_begin, &g_aln_type.qry_free_end, &g_aln_type.graph_free_begin, &g_aln_type.graph_free_end};
+    for (int i = 0; i < 4; ++i) { b[i]->kind = (uint32_t)spec[1 + 2 * i]; b[i]->v = spec[2 + 2 * i]; }
+}
 
 void* oracle_graph_from_csr(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sym,
                             const uint32_t* succ_off, const uint32_t* succ, const uint32_t* pred_off,
@@ -109,6 +122,17 @@ uint32_t oracle_poa_aligned_nodes(void* p, uint32_t node, uint32_t* out, uint32_
 }
 
 // ---- known-answer hooks ---------------------------------------------------
+// AlignmentGraph::is_end under the current alignment type (gap_affine.rs:185-248)
+int oracle_is_end(void* p, uint64_t seq_len, uint32_t node, uint32_t offset, int state) {
+    auto* h = (GraphHandle*)p;
+    try {
+        Aligner a(h->g, h->bi(), Costs{1, 1, 1}, H_DIJKSTRA, false);
+        apply_aln_type(a);
+        a.seq_len = seq_len;
+        return a.is_end(AlnNode{node, offset}, (AlignState)state) ? 1 : 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
 uint64_t oracle_gap_cost(uint8_t m, uint8_t o, uint8_t e, int state, uint64_t len) {
     Costs c{m, o, e};
     return c.gap_cost((AlignState)state, len);
@@ -152,6 +176,7 @@ uint64_t oracle_heuristic_h(void* p, uint8_t m, uint8_t o, uint8_t e, int heuris
                             uint32_t offset, int state) {
     auto* h = (GraphHandle*)p;
     Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, true);
+    apply_aln_type(a);
     a.seq_len = seq_len;
     return a.h({node, offset}, (AlignState)state);
 }
@@ -163,6 +188,7 @@ int oracle_dfa_first_event(void* p, const uint8_t* seq, uint64_t len, uint32_t n
     try {
         auto* h = (GraphHandle*)p;
         Aligner a(h->g, h->bi(), Costs{4, 6, 2}, H_DIJKSTRA, true);
+        apply_aln_type(a);
         a.seq = seq; a.seq_len = len;
         a.visited.init(h->g, a.ranks, len);
         a.forced_prune = force_prune ? 1 : 0;
@@ -216,6 +242,7 @@ int oracle_astar_align(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, 
             return 0;
         }
         Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        apply_aln_type(a);
         return run_astar(h, a, seq, len, score, pairs, cap, n_pairs, counters);
     } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
 }
@@ -232,6 +259,7 @@ int oracle_astar_batch(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, 
         std::atomic<uint32_t> next{0};
         auto work = [&]() {
             Aligner a(h->g, bi, Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+            apply_aln_type(a);
             for (;;) {
                 uint32_t i = next.fetch_add(1);
                 if (i >= n_queries) break;
@@ -453,6 +481,7 @@ extern "C" int oracle_astar_table(void* p, uint8_t m, uint8_t o, uint8_t e, int 
     auto* h = (GraphHandle*)p;
     try {
         Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        apply_aln_type(A);
         AstarResult r = A.astar_alignment(seq, len);
         const size_t n = h->g.symbol.size(), P = len + 1;
         for (uint32_t v = 0; v < n; ++v)

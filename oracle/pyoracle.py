@@ -77,8 +77,36 @@ def lib():
         L.oracle_astar_batch.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         L.oracle_dense_align.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
         L.oracle_dense_batch.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+        L.oracle_set_alignment_type.argtypes = [vp]
+        L.oracle_is_end.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
         _lib = L
     return _lib
+
+
+UNBOUNDED, INCLUDED, EXCLUDED = 0, 1, 2
+
+
+class alignment_type:
+    """Context manager: `with alignment_type(ends_free(...)):` — every search inside runs with that AlignmentType
+    (scoring/mod.rs:50-62); Global outside.  A bound is UNBOUNDED or (INCLUDED | EXCLUDED, n)."""
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def __enter__(self):
+        lib().oracle_set_alignment_type(_p(self.spec))
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_alignment_type(None)
+        return False
+
+
+def ends_free(qry_free_begin=UNBOUNDED, qry_free_end=UNBOUNDED, graph_free_begin=UNBOUNDED, graph_free_end=UNBOUNDED):
+    spec = [1]
+    for b in (qry_free_begin, qry_free_end, graph_free_begin, graph_free_end):
+        spec += [b, 0] if isinstance(b, int) else [b[0], b[1]]
+    return np.array(spec, np.uint64)
 
 
 def _p(a):
@@ -222,6 +250,9 @@ class OracleGraph:
         kind = {0: None, 1: "RefGraphEnd", 2: "QueryEnd", 3: "Mismatch"}[int(out[0])]
         return dict(kind=kind, parent=(int(out[1]), int(out[2])), child=(int(out[3]), int(out[4])),
                     num_visited=int(out[5]), num_pruned=int(out[6]))
+
+    def is_end(self, seq_len, node, offset, state=0):
+        return bool(lib().oracle_is_end(self.h, seq_len, node, offset, state))
 
     # -- alignment --
     def astar_align(self, seq, costs=None, heuristic=H_MINGAP, prune=True):

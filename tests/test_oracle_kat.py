@@ -230,3 +230,63 @@ def test_offset0_special_case_quirk(oracle):
     assert g.astar_align(b"AC", c, oracle.H_MINGAP)["score"] == 14
     d = g.dense_align(b"AC", c)
     assert d["score"] == 10 and d["flags"] & oracle.DF_START_QUIRK
+
+
+# ---------------------------------------------------------------------------------------------
+# Ends-free alignment: the reference's own known answers, 1-piece gap-affine
+# ---------------------------------------------------------------------------------------------
+def _all_free(oracle):
+    return oracle.alignment_type(oracle.ends_free())
+
+
+def test_ends_free_known_scores(oracle):
+    """gap_affine.rs:1124-1182 (prefix / suffix skipping == 0), :1184-1205 (empty query runs), :1320-1352 (single
+    nucleotide == 0), :1080-1122 (ends-free <= global); GapAffine::new(1, 2, 8) = mismatch 1, extend 2, open 8; Dijkstra."""
+    c = oracle.Costs(1, 8, 2)
+    g = _poa(oracle, [b"ATCG"])
+    with _all_free(oracle):
+        assert g.astar_align(b"TCG", c, oracle.H_DIJKSTRA)["score"] == 0
+        assert g.astar_align(b"ATCGAA", c, oracle.H_DIJKSTRA)["score"] == 0
+        r = g.astar_align(b"", c, oracle.H_DIJKSTRA)
+        assert r["score"] == 0 and r["alignment"] == []
+        assert _poa(oracle, [b"ATCGATCG"]).astar_align(b"A", c, oracle.H_DIJKSTRA)["score"] == 0
+        ef = g.astar_align(b"TTCG", c, oracle.H_DIJKSTRA)["score"]
+    assert ef <= g.astar_align(b"TTCG", c, oracle.H_DIJKSTRA)["score"]
+
+
+def test_ends_free_edge_cases(oracle):
+    """tests/edge_cases.rs: :64-112 AAAA x TTTT (mismatch 2, extend 1, open 8): "score 2 and no alignment, or 8";
+    :225-262 graph "A": query A == 0, other bases "score 10 with the single pair (None, 0), or score 1";
+    :264-283 ATCG x ANTG > 0; :17-37 empty graph still yields a score."""
+    with _all_free(oracle):
+        r = _poa(oracle, [b"AAAA"]).astar_align(b"TTTT", oracle.Costs(2, 8, 1), oracle.H_DIJKSTRA)
+        assert (r["score"] == 2 and r["alignment"] == []) or r["score"] == 8
+        g = _poa(oracle, [b"A"])
+        c = oracle.Costs(1, 8, 2)
+        assert g.astar_align(b"A", c, oracle.H_DIJKSTRA)["score"] == 0
+        for nuc in (b"T", b"C", b"G"):
+            r = g.astar_align(nuc, c, oracle.H_DIJKSTRA)
+            assert (r["score"] == 10 and r["alignment"] == [(oracle.NONE, 0)]) or r["score"] == 1
+        assert _poa(oracle, [b"ATCG"]).astar_align(b"ANTG", c, oracle.H_DIJKSTRA)["score"] > 0
+        assert oracle.OracleGraph.new_poa().astar_align(b"ATCG", c, oracle.H_DIJKSTRA)["score"] == 16
+
+
+def test_ends_free_is_end_with_bounded_graph_end(oracle):
+    """gap_affine.rs:1354-1395 on mock graph 1 (create_test_graph1), empty query, Match state:
+    graph_free_end Included(3): node 3 may end, node 2 may not; Excluded(3): node 4 may, node 3 may not."""
+    g = oracle.OracleGraph.mock(1)
+    with oracle.alignment_type(oracle.ends_free(graph_free_end=(oracle.INCLUDED, 3))):
+        assert g.is_end(0, 3, 0) and not g.is_end(0, 2, 0)
+    with oracle.alignment_type(oracle.ends_free(graph_free_end=(oracle.EXCLUDED, 3))):
+        assert g.is_end(0, 4, 0) and not g.is_end(0, 3, 0)
+    assert not g.is_end(0, 3, 0)  # Global again outside the context
+
+
+def test_ends_free_early_termination_quirk(oracle):
+    """Restated behaviour, no reference assertion covers it ("parity unpinned" for these values): with every end
+    Unbounded `is_end` accepts ANY popped Match state with offset > 0 (gap_affine.rs:203-207), so the search stops at
+    the first such pop — after one mismatch the answer is the mismatch cost, however long the query."""
+    g = _poa(oracle, [b"ACGTACGTAC"])
+    with _all_free(oracle):
+        r = g.astar_align(b"TTTTTTTT", oracle.Costs(4, 6, 2), oracle.H_DIJKSTRA)
+    assert r["score"] == 4
