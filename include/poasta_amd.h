@@ -67,12 +67,32 @@ typedef struct poa_costs {
 
 /* Which reference configuration the exact replay emulates (only the replay depends on it: heuristic and pruning
  * fix the reference's search order, not its optimum).  Zero-initialised == dense mode. */
+/* std::ops::Bound<usize> of AlignmentType::EndsFree (scoring/mod.rs:50-62) */
+typedef struct poa_bound {
+    uint32_t kind;            /* POA_BOUND_* */
+    uint32_t value;
+} poa_bound_t;
+#define POA_BOUND_UNBOUNDED 0u
+#define POA_BOUND_INCLUDED 1u
+#define POA_BOUND_EXCLUDED 2u
+#define POA_SPAN_GLOBAL 0u    /* AlignmentType::Global */
+#define POA_SPAN_ENDS_FREE 1u /* AlignmentType::EndsFree{..}: what the reference returns is defined by its SEARCH
+                                 (initial states gap_affine.rs:136-183, is_end :185-248: with unbounded ends the first
+                                 popped Match state past offset 0 ends it), so the engine replays that search for every
+                                 query whatever `mode` says; POA_FLAG_TRUNCATED then only says that the alignment does
+                                 not begin at the start node */
+
 typedef struct poa_config {
     uint32_t mode;            /* POA_MODE_* */
     uint32_t heuristic;       /* POA_HEURISTIC_* (replay only) */
     uint32_t pruning;         /* 1: align / align_with_existing_bubbles; 0: align_no_pruning (mod.rs:81-90) */
     float queue_entries_per_cell; /* replay queue pool, entries per (row x column) cell; 0 = default 0.25 */
     uint32_t flags;           /* POA_CFG_* */
+    uint32_t span;            /* POA_SPAN_* ; the four bounds are read only for POA_SPAN_ENDS_FREE */
+    poa_bound_t qry_free_begin;   /* carried, never read by the reference's 1-piece path (gap_affine.rs:146) */
+    poa_bound_t qry_free_end;
+    poa_bound_t graph_free_begin;
+    poa_bound_t graph_free_end;
 } poa_config_t;
 #define POA_CFG_FULL_PLANES 1u /* keep all three score planes in memory (needed by poa_batch_fetch_planes); the default
                                   u16 layout stores M, a 4-bit code per cell instead of I, and only the D rows read back */

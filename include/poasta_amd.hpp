@@ -132,7 +132,25 @@ struct GapAffine {
     uint8_t gap_extend() const { return cost_gap_extend; }
 };
 
-enum class AlignmentType { Global };  // scoring/mod.rs:50-62; ends-free is not on the GPU path yet
+// std::ops::Bound<usize> and AlignmentType (scoring/mod.rs:50-62).  `AlignmentType::Global` or
+// `AlignmentType::EndsFree(qry_free_begin, qry_free_end, graph_free_begin, graph_free_end)`; an ends-free result is
+// defined by the reference's search, so the library replays that search for every query (exact mode implied).
+struct Bound {
+    uint32_t kind = POA_BOUND_UNBOUNDED;
+    uint32_t value = 0;
+    static Bound Unbounded() { return Bound{}; }
+    static Bound Included(size_t n) { return Bound{POA_BOUND_INCLUDED, (uint32_t)n}; }
+    static Bound Excluded(size_t n) { return Bound{POA_BOUND_EXCLUDED, (uint32_t)n}; }
+};
+struct AlignmentType {
+    bool ends_free = false;
+    Bound qry_free_begin, qry_free_end, graph_free_begin, graph_free_end;
+    static const AlignmentType Global;
+    static AlignmentType EndsFree(Bound qb = Bound{}, Bound qe = Bound{}, Bound gb = Bound{}, Bound ge = Bound{}) {
+        return AlignmentType{true, qb, qe, gb, ge};
+    }
+};
+inline const AlignmentType AlignmentType::Global{};
 
 struct AffineMinGapCost { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_MINGAP; explicit AffineMinGapCost(GapAffine c) : costs(c) {} };
 struct AffineDijkstra { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_DIJKSTRA; explicit AffineDijkstra(GapAffine c) : costs(c) {} };
@@ -160,7 +178,7 @@ template <typename Config>
 class PoastaAligner {
 public:
     PoastaAligner(Config config, AlignmentType aln_type, int device = 0, Mode mode = Mode::Dense)
-        : config_(config), device_(device), mode_(mode) { (void)aln_type; }
+        : config_(config), aln_type_(aln_type), device_(device), mode_(mode) {}
 
     // mod.rs:114-145
     AstarResult align(const graphs::POAGraph& g, const std::string& seq) const { return align_batch(g, {seq}, true).at(0); }
@@ -181,7 +199,15 @@ public:
         std::vector<uint64_t> pair_off(n + 1, 0);
         std::vector<poa_aln_pair_t> pairs(cap);
         const poa_costs_t c{config_.costs.mismatch(), config_.costs.gap_open(), config_.costs.gap_extend(), 0};
-        const poa_config_t cfg{(uint32_t)mode_, Config::heuristic, pruning ? 1u : 0u, 0.f, 0u};
+        poa_config_t cfg{};
+        cfg.mode = (uint32_t)mode_; cfg.heuristic = Config::heuristic; cfg.pruning = pruning ? 1u : 0u;
+        if (aln_type_.ends_free) {
+            cfg.span = POA_SPAN_ENDS_FREE;
+            cfg.qry_free_begin = poa_bound_t{aln_type_.qry_free_begin.kind, aln_type_.qry_free_begin.value};
+            cfg.qry_free_end = poa_bound_t{aln_type_.qry_free_end.kind, aln_type_.qry_free_end.value};
+            cfg.graph_free_begin = poa_bound_t{aln_type_.graph_free_begin.kind, aln_type_.graph_free_begin.value};
+            cfg.graph_free_end = poa_bound_t{aln_type_.graph_free_end.kind, aln_type_.graph_free_end.value};
+        }
         const int rc = poa_align_batch_ex(g.device_graph(), &c, &cfg, n, (const uint8_t*)qseq.data(), qoff.data(), score.data(),
                                           pairs.data(), pair_off.data(), cap, flags.data(), stats, device_);
         if (rc != POA_OK) throw PoastaError(std::string("poa_align_batch: ") + poa_last_error());
@@ -201,6 +227,7 @@ public:
 
 private:
     Config config_;
+    AlignmentType aln_type_;
     int device_;
     Mode mode_;
 };

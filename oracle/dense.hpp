@@ -166,7 +166,7 @@ public:
                 if (j > 0) {
                     bool moe = g.is_symbol_equal(v, q[j - 1]) || v == g.end;
                     size_t pj = (v == g.end) ? j : j - 1;
-                    Score target = moe ? cs : sub(cs, x);
+                    Score target = (moe || g.pred[v].empty()) ? cs : sub(cs, x);  // evaluated per predecessor in the reference
                     for (uint32_t p : g.pred[v]) if (Mx(p, pj) == target) cand(p, pj, ST_M);
                 }
                 if (Dx(v, j) == cs) cand(v, j, ST_D);

@@ -28,9 +28,18 @@ class PoaCosts(C.Structure):
     _fields_ = [("mismatch", C.c_uint8), ("gap_open", C.c_uint8), ("gap_extend", C.c_uint8), ("reserved", C.c_uint8)]
 
 
+class PoaBound(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("value", C.c_uint32)]
+
+
 class PoaConfig(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("heuristic", C.c_uint32), ("pruning", C.c_uint32), ("queue_entries_per_cell", C.c_float),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("span", C.c_uint32), ("qry_free_begin", PoaBound), ("qry_free_end", PoaBound),
+                ("graph_free_begin", PoaBound), ("graph_free_end", PoaBound)]
+
+
+BOUND_UNBOUNDED, BOUND_INCLUDED, BOUND_EXCLUDED = 0, 1, 2
+SPAN_GLOBAL, SPAN_ENDS_FREE = 0, 1
 
 
 MODE_DENSE, MODE_EXACT, MODE_HYBRID = 0, 1, 2

@@ -48,10 +48,34 @@ class GapAffine:
         return _lib.PoaCosts(self.cost_mismatch, self.cost_gap_open, self.cost_gap_extend, 0)
 
 
+class Bound:
+    """std::ops::Bound<usize> as the reference's AlignmentType::EndsFree uses it."""
+    Unbounded = (_lib.BOUND_UNBOUNDED, 0)
+
+    @staticmethod
+    def Included(n):
+        return (_lib.BOUND_INCLUDED, int(n))
+
+    @staticmethod
+    def Excluded(n):
+        return (_lib.BOUND_EXCLUDED, int(n))
+
+
+class EndsFree:
+    """AlignmentType::EndsFree {qry_free_begin, qry_free_end, graph_free_begin, graph_free_end} (scoring/mod.rs:56-61).
+    What the reference returns for it is defined by its search (gap_affine.rs:136-248), so the engine replays that
+    search for every query (exact mode is implied)."""
+
+    def __init__(self, qry_free_begin=Bound.Unbounded, qry_free_end=Bound.Unbounded, graph_free_begin=Bound.Unbounded,
+                 graph_free_end=Bound.Unbounded):
+        self.bounds = (qry_free_begin, qry_free_end, graph_free_begin, graph_free_end)
+
+
 class AlignmentType:
-    """scoring/mod.rs:50-62.  Only Global is implemented on the GPU path (what `lasagna` hard-codes,
-    src/bin/lasagna.rs:256)."""
+    """scoring/mod.rs:50-62: `AlignmentType.Global` (what `lasagna` hard-codes, src/bin/lasagna.rs:256) or
+    `AlignmentType.EndsFree(...)`."""
     Global = "global"
+    EndsFree = EndsFree
 
 
 class AffineMinGapCost:
@@ -71,11 +95,17 @@ class AffineDijkstra(AffineMinGapCost):
 MODES = {"dense": _lib.MODE_DENSE, "exact": _lib.MODE_EXACT, "hybrid": _lib.MODE_HYBRID}
 
 
-def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, queue_entries_per_cell=0.0, full_planes=False):
+def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, queue_entries_per_cell=0.0, full_planes=False,
+                aln_type=AlignmentType.Global):
     """poa_config_t: `mode` "dense" | "exact" (replay the reference's A* for every query: bit-identical
-    tie-breaks) | "hybrid" (replay only the queries the dense pass could not certify)."""
-    return _lib.PoaConfig(MODES[mode] if isinstance(mode, str) else int(mode), int(heuristic), 1 if pruning else 0,
-                          float(queue_entries_per_cell), _lib.CFG_FULL_PLANES if full_planes else 0)
+    tie-breaks) | "hybrid" (replay only the queries the dense pass could not certify); `aln_type` Global or EndsFree(...)."""
+    cfg = _lib.PoaConfig(MODES[mode] if isinstance(mode, str) else int(mode), int(heuristic), 1 if pruning else 0,
+                         float(queue_entries_per_cell), _lib.CFG_FULL_PLANES if full_planes else 0)
+    if isinstance(aln_type, EndsFree):
+        cfg.span = _lib.SPAN_ENDS_FREE
+        for name, (kind, value) in zip(("qry_free_begin", "qry_free_end", "graph_free_begin", "graph_free_end"), aln_type.bounds):
+            setattr(cfg, name, _lib.PoaBound(kind, value))
+    return cfg
 
 
 class AlignedPair:
@@ -240,8 +270,8 @@ class PoastaAligner:
     """`PoastaAligner::new(config, aln_type)` (mod.rs:53)."""
 
     def __init__(self, config, aln_type=AlignmentType.Global, device=0, mode="dense", queue_entries_per_cell=0.0):
-        if aln_type != AlignmentType.Global:
-            raise NotImplementedError("only AlignmentType::Global runs on the GPU path (SURVEY.md §8(f) row 2)")
+        if aln_type != AlignmentType.Global and not isinstance(aln_type, EndsFree):
+            raise ValueError("aln_type must be AlignmentType.Global or AlignmentType.EndsFree(...)")
         self.config, self.aln_type, self.device = config, aln_type, device
         self.mode, self.queue_entries_per_cell = mode, queue_entries_per_cell
 
@@ -272,7 +302,7 @@ class PoastaAligner:
         pairs = np.zeros((max(cap, 1), 2), np.uint32) if want_pairs else None
         st = _lib.PoaStats()
         c = self.config.costs._c()
-        cfg = make_config(self.mode, self.config.heuristic, pruning, self.queue_entries_per_cell)
+        cfg = make_config(self.mode, self.config.heuristic, pruning, self.queue_entries_per_cell, aln_type=self.aln_type)
         _lib.check(_lib.lib().poa_align_batch_ex(dg.handle, C.byref(c), C.byref(cfg), n, _p(qseq), _p(qoff), _p(score),
                                                  _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), self.device))
         if want_pairs:

@@ -86,7 +86,7 @@ struct poa_batch {
     DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
     DevBuf<uint2> d_scratch, d_pairs;
     // exact-replay mode (allocated on first use)
-    DevBuf<uint32_t> d_succ_off, d_succ_rows, d_dist_min, d_dist_max, d_nbm_off, d_ex_status, d_exit_idx, d_ex_head;
+    DevBuf<uint32_t> d_succ_off, d_succ_rows, d_dist_min, d_dist_max, d_nbm_off, d_ex_status, d_exit_idx, d_ex_head, d_node_row, d_sp_to_end, d_ex_end;
     DevBuf<FlatGraph::NodeBubble> d_nbm;
     DevBuf<uint8_t> d_ex_sym;
     DevBuf<uint64_t> d_ex_reached, d_ex_rsum;
@@ -339,6 +339,10 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
         HIP_TRY(b->d_succ_off.alloc(fg.succ_row_off.size()));
         HIP_TRY(b->d_succ_rows.alloc(std::max<size_t>(fg.succ_rows.size(), 1)));
         HIP_TRY(b->d_dist_min.alloc(n)); HIP_TRY(b->d_dist_max.alloc(n)); HIP_TRY(b->d_exit_idx.alloc(n));
+        HIP_TRY(b->d_node_row.alloc(n)); HIP_TRY(b->d_sp_to_end.alloc(n));
+        HIP_TRY(b->d_ex_end.alloc(2 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
+        HIP_TRY(hipMemcpy(b->d_node_row.p, fg.node_row.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_sp_to_end.p, fg.sp_to_end.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(b->d_ex_sym.alloc((size_t)n + 4));
         {
             std::vector<uint8_t> row_sym((size_t)n + 4, 0);
@@ -372,8 +376,16 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) { re
 
 int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_t* cfg, void* stream_v) {
     if (!b || !costs) return fail(POA_ERR_INVALID_ARG, "poa_batch_run: null argument");
-    const uint32_t mode = cfg ? cfg->mode : POA_MODE_DENSE;
+    uint32_t mode = cfg ? cfg->mode : POA_MODE_DENSE;
     if (mode > POA_MODE_HYBRID) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown mode");
+    if (cfg && cfg->span > POA_SPAN_ENDS_FREE) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown alignment span");
+    const bool ends_free = cfg && cfg->span == POA_SPAN_ENDS_FREE;
+    if (ends_free) {
+        if (cfg->qry_free_end.kind > POA_BOUND_EXCLUDED || cfg->graph_free_begin.kind > POA_BOUND_EXCLUDED ||
+            cfg->graph_free_end.kind > POA_BOUND_EXCLUDED || cfg->qry_free_begin.kind > POA_BOUND_EXCLUDED)
+            return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown bound kind");
+        mode = POA_MODE_EXACT;  // an ends-free result is defined by the reference's search: replay it for every query
+    }
     if (cfg && cfg->heuristic > POA_HEURISTIC_MINGAP) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown heuristic");
     hipStream_t stream = (hipStream_t)stream_v;
     HIP_TRY(hipSetDevice(b->device));
@@ -444,7 +456,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         tp.score = b->d_score.p; tp.flags = b->d_flags.p; tp.n_pairs = b->d_npairs.p;
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
         tp.spec_depth = spec_depth;
-        tp.exact_pass = 0; tp.ex_status = nullptr;
+        tp.exact_pass = 0; tp.ex_status = nullptr; tp.ex_end = nullptr;
         FwdParams fp;
         fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
         fp.first_query = ch.first; fp.n_queries = ch.count;
@@ -530,7 +542,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             HIP_TRY(hipMemsetAsync(b->d_ex_head.p, 0xFF, (size_t)ch.count * 3 * b->ex_n_prio * 4, stream));
             ExactParams ep;
             ep.G = ExactGraph{fg.n, fg.start_row, fg.end_row, b->d_ex_sym.p, b->d_succ_off.p, b->d_succ_rows.p, b->d_dist_min.p,
-                              b->d_dist_max.p, b->d_exit_idx.p, fg.n_exit, b->d_nbm_off.p, b->d_nbm.p};
+                              b->d_dist_max.p, b->d_exit_idx.p, fg.n_exit, b->d_nbm_off.p, b->d_nbm.p, b->d_node_row.p, b->d_sp_to_end.p};
             ep.first_query = ch.first; ep.n_queries = ch.count; ep.hybrid = hybrid; ep.dense_flags = b->d_flags.p;
             ep.qseq = b->d_qseq.p; ep.qoff = b->d_qoff.p; ep.pitch = b->d_pitch.p; ep.plane_off = PL.d_off.p;
             ep.planes = b->d_planes.p;
@@ -538,8 +550,15 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             ep.head = b->d_ex_head.p; ep.n_prio = b->ex_n_prio; ep.pool = b->d_ex_pool.p; ep.pool_cap = b->ex_pool_cap;
             ep.stack = b->d_ex_stack.p; ep.stack_cap = b->ex_stack_cap;
             ep.C = ExactCosts{costs->mismatch, costs->gap_open, costs->gap_extend, cfg ? cfg->heuristic : POA_HEURISTIC_MINGAP,
-                              cfg ? cfg->pruning : 1u};
+                              cfg ? cfg->pruning : 1u, 0, 0, 0, 0, 0, 0};
+            if (ends_free) {
+                ep.C.ends_free = 1;
+                ep.C.qfe_kind = cfg->qry_free_end.kind; ep.C.qfe_val = cfg->qry_free_end.value;
+                ep.C.gfb_kind = cfg->graph_free_begin.kind;
+                ep.C.gfe_kind = cfg->graph_free_end.kind; ep.C.gfe_val = cfg->graph_free_end.value;
+            }
             ep.status = b->d_ex_status.p;
+            ep.end_cell = b->d_ex_end.p;
             // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
             // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.
             uint32_t lanes = (ch.count + 4095) / 4096;
@@ -566,7 +585,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             const uint32_t per_block = lanes * (EXACT_BLOCK / 64);
             hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + per_block - 1) / per_block), dim3(EXACT_BLOCK), lds_graph ? lds_bytes : 0, stream, ep);
             HIP_TRY(hipGetLastError());
-            tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p;
+            tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p; tp.ex_end = b->d_ex_end.p;
             hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             HIP_TRY(hipGetLastError());
             b->narrow = false; b->compact = false;  // the planes now hold the replayed u32 table

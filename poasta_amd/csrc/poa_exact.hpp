@@ -48,6 +48,9 @@ struct ExactGraph {  // row-indexed, read-only, shared by all queries
     uint32_t n_exit;
     const uint32_t* nbm_off;   // [n_rows+1]
     const FlatGraph::NodeBubble* nbm;
+    // ends-free spans only (null for Global)
+    const uint32_t* node_row;  // [n_rows] node index -> row (initial states are pushed by node index)
+    const uint32_t* sp_to_end; // [n_rows] edges on the shortest path to the end row (0xFFFFFFFF: none)
 };
 
 struct ExQEntry { uint32_t score, row, offset, next; };
@@ -69,9 +72,18 @@ struct ExactResult {
     uint32_t status;  // EX_*
     uint32_t score;
     uint32_t num_queued, num_visited, num_pruned;
+    uint32_t end_row, end_off;  // the end cell the backtrace starts from (astar.rs:141, :159)
 };
 
-struct ExactCosts { uint32_t x, o, e; uint32_t heuristic; uint32_t prune; };
+enum : uint32_t { EX_BOUND_UNBOUNDED = 0, EX_BOUND_INCLUDED = 1, EX_BOUND_EXCLUDED = 2 };
+struct ExactCosts {
+    uint32_t x, o, e; uint32_t heuristic; uint32_t prune;
+    // AlignmentType (scoring/mod.rs:50-62); ends_free == 0: Global
+    uint32_t ends_free;
+    uint32_t qfe_kind, qfe_val;   // qry_free_end
+    uint32_t gfb_kind;            // graph_free_begin (only Unbounded-or-not matters, gap_affine.rs:150-167)
+    uint32_t gfe_kind, gfe_val;   // graph_free_end
+};
 
 class ExactSearch {
 public:
@@ -321,8 +333,19 @@ public:
         return got;
     }
 
-    POA_HD bool is_end(uint32_t row, uint32_t off, uint32_t st) const {  // gap_affine.rs:190-194
-        return st == EX_ST_M && row == G.end_row && off == L;
+    POA_HD bool is_end(uint32_t row, uint32_t off, uint32_t st) const {  // gap_affine.rs:185-248
+        if (!C.ends_free) return st == EX_ST_M && row == G.end_row && off == L;
+        bool q_ok;
+        if (C.qfe_kind == EX_BOUND_UNBOUNDED) q_ok = off > 0 || L == 0;  // sic: any consumed prefix may end
+        else if (C.qfe_kind == EX_BOUND_INCLUDED) q_ok = L - off <= C.qfe_val;
+        else q_ok = L - off < C.qfe_val;
+        // dist_to_end(node, max) (gap_affine.rs:91-119) finds the end iff the shortest path has <= max edges
+        const uint32_t d = G.sp_to_end[row];
+        bool g_ok;
+        if (C.gfe_kind == EX_BOUND_UNBOUNDED) g_ok = true;
+        else if (C.gfe_kind == EX_BOUND_INCLUDED) g_ok = d != EX_INF && d <= C.gfe_val;
+        else g_ok = d != EX_INF && d <= (C.gfe_val ? C.gfe_val - 1 : 0u) && d < C.gfe_val;
+        return st == EX_ST_M && q_ok && g_ok;
     }
 
     // ---- expansions (gap_affine.rs:307-430) ----------------------------------------------------
@@ -414,16 +437,26 @@ public:
 
     // ---- main loop (astar.rs:124-226) -----------------------------------------------------------
     POA_HD ExactResult run() {
-        ExactResult R{EX_OK, EX_INF, 0, 0, 0};
-        queue_state(G.start_row, 0, EX_ST_M, 0);
-        *cell(G.start_row, 0, EX_ST_M) = 0;  // visited_data.set_score
+        ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+        if (C.ends_free && C.gfb_kind == EX_BOUND_UNBOUNDED && G.n_rows > 2) {
+            // gap_affine.rs:150-163: every real node at offset 0, pushed in reverse node-index order
+            for (uint32_t v = G.n_rows; v-- > 0;) {
+                const uint32_t r = G.node_row[v];
+                if (r == G.start_row || r == G.end_row) continue;
+                queue_state(r, 0, EX_ST_M, 0);
+                *cell(r, 0, EX_ST_M) = 0;
+            }
+        } else {
+            queue_state(G.start_row, 0, EX_ST_M, 0);
+            *cell(G.start_row, 0, EX_ST_M) = 0;  // visited_data.set_score
+        }
         uint32_t end_score = EX_INF;
         bool found = false;
         while (!found && !err) {
             uint32_t score, row, off, st;
             if (!pop_state(score, row, off, st)) { err = EX_PANIC; break; }  // "Could not align sequence!"
             if (score > get_score(row, off, st)) continue;
-            if (is_end(row, off, st)) { num_visited += 1; end_score = score; found = true; break; }
+            if (is_end(row, off, st)) { num_visited += 1; end_score = score; found = true; R.end_row = row; R.end_off = off; break; }
             if (C.prune && prune(score, row, off, st)) { num_pruned += 1; continue; }
             if (err) break;
             mark_reached(row, off, st);
@@ -435,7 +468,7 @@ public:
                     const Event ev = dfa_extend();
                     if (err || ev.kind == EV_NONE) break;
                     if (ev.kind == EV_REF_GRAPH_END) {
-                        if (is_end(ev.crow, ev.coff, EX_ST_M)) { end_score = score; found = true; break; }
+                        if (is_end(ev.crow, ev.coff, EX_ST_M)) { end_score = score; found = true; R.end_row = ev.crow; R.end_off = ev.coff; break; }
                         expand_ref_graph_end(ev.prow, ev.poff, score);
                     } else if (ev.kind == EV_QUERY_END) {
                         expand_query_end(ev.poff, ev.crow, score);

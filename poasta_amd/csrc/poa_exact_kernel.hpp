@@ -27,6 +27,7 @@ struct ExactParams {
     ExStackEntry* stack; uint32_t stack_cap;
     ExactCosts C;
     uint32_t* status;                 // [total] EX_* (0xFFFFFFFF = not replayed)
+    uint32_t* end_cell;               // [2 * total] (row, offset) the search stopped at
     uint32_t lanes_per_wave;          // active lanes per wave (divergence vs occupancy knob)
     uint32_t lds_graph;               // 1: the launch carries enough dynamic LDS to hold the graph arrays
     uint32_t n_succ, n_nbm;           // lengths of G.succ / G.nbm
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(EXACT_BLOCK) void poa_exact_kernel(ExactParams P) {
     ExactSearch S(G, W, P.qseq + qbeg, L, P.C);
     const ExactResult R = S.run();
     P.status[qi] = R.status;
+    P.end_cell[2 * qi] = R.end_row;
+    P.end_cell[2 * qi + 1] = R.end_off;
 }
 
 // INF-fill the u32 planes of the queries the replay will run on (coalesced, one block column per query)

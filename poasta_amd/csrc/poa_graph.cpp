@@ -154,6 +154,18 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
         }
         g.min_path_nodes = (dist[g.end_row] == 0xFFFFFFFFu || dist[g.end_row] == 0) ? 0 : dist[g.end_row] - 1;
     }
+    // shortest path to the end row, in edges (what the reference's dist_to_end BFS finds, gap_affine.rs:91-119)
+    g.sp_to_end.assign(n, 0xFFFFFFFFu);
+    g.sp_to_end[g.end_row] = 0;
+    for (uint32_t r = n; r-- > 0;) {
+        const uint32_t d = g.sp_to_end[r];
+        if (d == 0xFFFFFFFFu) continue;
+        const RowMeta& m = g.rows[r];
+        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+            uint32_t& pd = g.sp_to_end[g.pred_rows[m.pred_begin + pe]];
+            if (d + 1 < pd) pd = d + 1;
+        }
+    }
     return POA_OK;
 }
 

@@ -44,6 +44,7 @@ struct FlatGraph {
     uint32_t start_row = 0, end_row = 0;
     uint32_t max_indegree = 0;
     uint32_t min_path_nodes = 0;         // real nodes on the shortest start -> end path
+    std::vector<uint32_t> sp_to_end;     // row -> edges on the shortest path to the end row (0xFFFFFFFF: none)
 
     // ---- exact-replay mode only: the reference's per-graph preprocessing --------------------
     // successors as rows, trait order preserved (DFA / expand_all iterate them in this order)

@@ -73,6 +73,7 @@ struct TbParams {
     // replay succeeded are (re)traced, the others keep their dense result and get a flag.
     uint32_t exact_pass;
     const uint32_t* ex_status;    // [total] 0 ok, 1 reference panic, 2 workspace overflow, 0xFFFFFFFF not replayed
+    const uint32_t* ex_end;       // [2 * total] (row, offset) of the end cell the replayed search stopped at
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -208,7 +209,8 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
         if (j > 0) {
             const bool moe = is_end || ((uint32_t)m.sym == (uint32_t)c.q[j - 1]);
             const uint32_t pj = is_end ? j : j - 1;
-            const uint32_t target = moe ? cs : sub(cs, c.x);
+            // the reference evaluates `curr_score - mismatch` per predecessor: never for a row without predecessors
+            const uint32_t target = (moe || m.pred_count == 0) ? cs : sub(cs, c.x);
             if ((m.flags & ROW_CHAIN) && !is_end) {  // the end row reads its predecessor at the SAME column
                 if (up == target) cand(row - 1, pj, 0);
             } else {
@@ -302,15 +304,19 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     };
     auto bc = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); };
 
-    if (lane == 0) P.score[qi] = pl(c.M, c.pitch, c.end_row, L);
-    const uint32_t end_node = c.rows[c.end_row].node;
+    // the cell the backtrace starts from: (end row, L) for Global; where the replayed search stopped for ends-free
+    const uint32_t tb_row = (P.exact_pass && P.ex_end) ? P.ex_end[2 * qi] : c.end_row;
+    const uint32_t tb_off = (P.exact_pass && P.ex_end) ? P.ex_end[2 * qi + 1] : L;
+    if (lane == 0) P.score[qi] = pl(c.M, c.pitch, tb_row, tb_off);
+    const uint32_t end_node = c.rows[tb_row].node;
 
     bool done = false;
     uint32_t crow = 0, cj = 0, cst = 0;
     uint32_t gcs = INF;  // score of the current D / I cell (wave-uniform)
     if (L == 0) done = true;
-    if (!done && L == 1) {
-        // gap_affine.rs:812-824: the end node equals every symbol -> always [(end, 0)]
+    if (!done && L == 1 && tb_off == 1 && (tb_row == c.end_row || (uint32_t)c.rows[tb_row].sym == (uint32_t)c.q[0])) {
+        // gap_affine.rs:812-824: "single nucleotide perfect match"; the end node equals every symbol, so in Global
+        // mode this always yields [(end, 0)]
         flags |= POA_FLAG_SHORT_QUERY;
         if (lane == 0) emit_at(0, end_node, 0);
         cnt = 1;
@@ -321,15 +327,17 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         uint32_t f0 = 0, fr = 0, fj = 0, fs = 0, fallback = 0, fg = INF;
         if (lane == 0) {
             uint32_t nc; bool bad = false, pn = false;
-            TbStep cur = tb_step<T, COMPACT>(c, c.end_row, L, 0, INF, nc, bad, pn);
+            TbStep cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 0, INF, nc, bad, pn);
             fg = cur.cs;
             if (pn) f0 |= POA_FLAG_REF_PANIC;
             if (cur.found && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
             if (!cur.found) {
                 // the end row has no insertion state (I[end] = INF) and keeps its D row in every layout
-                cur = tb_step<T, COMPACT>(c, c.end_row, L, 2, INF, nc, bad, pn);
-                if (!cur.found) { cur = tb_step<T, COMPACT>(c, c.end_row, L, 1, pl(c.D, c.pitch, c.end_row, L), nc, bad, pn); fg = cur.cs; }
-                if (!cur.found) { f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
+                cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 2, INF, nc, bad, pn);  // (full planes: the stored I value is used)
+                if (!cur.found) { cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, pl(c.D, c.pitch, tb_row, tb_off), nc, bad, pn); fg = cur.cs; }
+                // no backtrace from the end cell: the reference builds a 'simple alignment' for len <= 3 and panics otherwise
+                // (gap_affine.rs:838-853); on a replayed table that is exactly what happened, so only len > 3 is a panic
+                if (!cur.found) { if (!(P.exact_pass && L <= 3)) f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
                 else f0 |= POA_FLAG_AMBIGUOUS;
                 if (cur.found && cur.st == 1) fg = cur.cs - c.e;  // stepped D -> D
             }

@@ -19,7 +19,7 @@ extern "C" {
 int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
                    const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred, uint8_t x, uint8_t o, uint8_t e,
                    int heuristic, int prune, const uint8_t* seq, uint32_t len, uint32_t* out, uint32_t* pm, uint32_t* pi,
-                   uint32_t* pd) {
+                   uint32_t* pd, const uint32_t* span /* null = Global; else {1, qfe_kind, qfe_val, gfb_kind, gfe_kind, gfe_val}; out[4..5] = end node, offset */) {
     FlatGraph g;
     std::string err;
     int rc = build_flat_graph(n, start, end, symbol, succ_off, succ, pred_off, pred, g, err);
@@ -29,7 +29,8 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     std::vector<uint8_t> row_sym(g.n);
     for (uint32_t r = 0; r < g.n; ++r) row_sym[r] = g.rows[r].sym;
     ExactGraph G{g.n, g.start_row, g.end_row, row_sym.data(), g.succ_row_off.data(), g.succ_rows.data(),
-                 g.dist_min.data(), g.dist_max.data(), g.exit_idx.data(), g.n_exit, g.nbm_off.data(), g.nbm.data()};
+                 g.dist_min.data(), g.dist_max.data(), g.exit_idx.data(), g.n_exit, g.nbm_off.data(), g.nbm.data(),
+                 g.node_row.data(), g.sp_to_end.data()};
     const uint32_t pitch = len + 1, wpn = (len + 1 + 63) / 64, swpn = (wpn + 63) / 64;
     std::vector<uint32_t> M((size_t)n * pitch, EX_INF), I(M), D(M);
     std::vector<uint64_t> reached((size_t)g.n_exit * wpn + 1, 0), rsum((size_t)g.n_exit * swpn + 1, 0);
@@ -39,9 +40,12 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     std::vector<ExStackEntry> stack(n + len + 8);
     ExactWork W{M.data(), I.data(), D.data(), pitch, reached.data(), rsum.data(), wpn, swpn, head.data(), n_prio,
                 pool.data(), (uint32_t)pool.size(), stack.data(), (uint32_t)stack.size()};
-    ExactSearch S(G, W, seq, len, ExactCosts{x, o, e, (uint32_t)heuristic, (uint32_t)prune});
+    ExactCosts EC{x, o, e, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0};
+    if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
+    ExactSearch S(G, W, seq, len, EC);
     ExactResult R = S.run();
     out[0] = R.score; out[1] = R.num_queued; out[2] = R.num_visited; out[3] = R.num_pruned;
+    if (span) { out[4] = g.rows[R.end_row].node; out[5] = R.end_off; }
     if (pm) {
         for (uint32_t v = 0; v < n; ++v) {
             const uint32_t r = g.node_row[v];

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from poasta_amd import workloads as W
-from poasta_amd.graph import pack_queries
+from poasta_amd.graph import GraphBuilder, pack_queries
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 vp = C.c_void_p
@@ -29,7 +29,7 @@ def harness():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src,
                                os.path.join(ROOT, "poasta_amd", "csrc", "poa_graph.cpp")])
     X = C.CDLL(out)
-    X.exact_host_run.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [C.c_uint8] * 3 + [C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]
+    X.exact_host_run.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [C.c_uint8] * 3 + [C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     X.exact_host_bubbles.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp] * 5 + [C.c_uint32]
     return X
 
@@ -43,16 +43,33 @@ def _oracle_table(oracle, og, q, costs, heur, prune, n):
     return rc, m, i, d, out
 
 
-def _compare(oracle, X, g, qs, costs, heur, prune):
+def _span_args(oracle, span):
+    """span = None (Global) or dict(qry_free_end=, graph_free_begin=, graph_free_end=) with oracle-style bounds."""
+    if span is None:
+        return None, None
+    b = lambda v: (v, 0) if isinstance(v, int) else v
+    qfe, gfb, gfe = b(span.get("qry_free_end", 0)), b(span.get("graph_free_begin", 0)), b(span.get("graph_free_end", 0))
+    arr = np.array([1, qfe[0], qfe[1], gfb[0], gfe[0], gfe[1]], np.uint32)
+    return arr, oracle.ends_free(0, span.get("qry_free_end", 0), span.get("graph_free_begin", 0), span.get("graph_free_end", 0))
+
+
+def _compare(oracle, X, g, qs, costs, heur, prune, span=None):
     og = oracle.OracleGraph.from_csr(g.as_dict())
     n_ok = 0
+    sarr, ospec = _span_args(oracle, span)
     for q in qs:
         q = np.ascontiguousarray(q, np.uint8)
-        rc1, om, oi, od, oo = _oracle_table(oracle, og, q, costs, heur, prune, g.n)
+        if ospec is None:
+            rc1, om, oi, od, oo = _oracle_table(oracle, og, q, costs, heur, prune, g.n)
+        else:
+            with oracle.alignment_type(ospec):
+                rc1, om, oi, od, oo = _oracle_table(oracle, og, q, costs, heur, prune, g.n)
         xm, xi, xd = (np.zeros((g.n, len(q) + 1), np.uint32) for _ in range(3))
-        xo = np.zeros(4, np.uint32)
+        xo = np.zeros(6 if sarr is not None else 4, np.uint32)
         rc2 = X.exact_host_run(g.n, g.start, g.end, _p(g.symbol), _p(g.succ_off), _p(g.succ), _p(g.pred_off), _p(g.pred),
-                               *costs, heur, prune, _p(q), len(q), _p(xo), _p(xm), _p(xi), _p(xd))
+                               *costs, heur, prune, _p(q), len(q), _p(xo), _p(xm), _p(xi), _p(xd),
+                               _p(sarr) if sarr is not None else None)
+        xo = xo[:4]
         if rc1 == 1 and rc2 == 0:
             continue  # the oracle's panic came from the BACKTRACE (u32 wrap), which the search does not include
         assert rc1 == 0 and rc2 == 0, (rc1, rc2)
@@ -119,6 +136,28 @@ def _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(4, 6, 2), cfg_cls="AffineM
     return n, res
 
 
+def test_replay_equals_oracle_search_ends_free_cpu(oracle, harness):
+    """AlignmentType::EndsFree: the replay's visited table, score and counters equal the oracle's for every kind of
+    bound the reference distinguishes (gap_affine.rs:136-248)."""
+    U, INC, EXC = oracle.UNBOUNDED, oracle.INCLUDED, oracle.EXCLUDED
+    spans = [dict(), dict(graph_free_begin=(INC, 0)), dict(qry_free_end=(INC, 2)), dict(qry_free_end=(EXC, 3), graph_free_end=(INC, 2)),
+             dict(graph_free_begin=(INC, 0), qry_free_end=(INC, 0), graph_free_end=(EXC, 3)), dict(graph_free_end=(INC, 0))]
+    n_ok = 0
+    for seed in range(40):
+        rng = np.random.Generator(np.random.PCG64(3000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, 0.3, alpha) for _ in range(6)]
+        costs = [(4, 6, 2), (2, 8, 1), (1, 10, 2), (3, 1, 1)][seed % 4]
+        span = spans[seed % len(spans)]
+        for heur, prune in ((1, 1), (0, 0)):
+            n_ok += _compare(oracle, harness, g, qs, costs, heur, prune, span=span)
+    assert n_ok > 300
+    g, (qseq, qoff) = W.scaled_linearish(120, 6, 3, 6, 60)
+    qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(6)]
+    assert _compare(oracle, harness, g, qs, (4, 6, 2), 1, 1, span=dict(qry_free_end=(INC, 0))) == 6
+
+
 @pytest.mark.gpu
 def test_gpu_exact_mode_is_bit_identical(engine, oracle):
     n = 0
@@ -151,6 +190,65 @@ def test_gpu_exact_reproduces_suboptimal_pruned_search(engine, oracle):
     n, res = _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(8, 3, 1), cfg_cls="AffineDijkstra", pruning=False, allow_flags=0x10,
                                  queue_entries_per_cell=12.0)  # Dijkstra order without pruning queues every cell several times
     assert int(res.score[4]) == 500 and int(res.score[9]) == 488
+
+
+def _gpu_ends_free_vs_astar(engine, oracle, g, qs, costs, cfg_cls, pruning, bounds):
+    """bounds: dict of (kind, value) pairs keyed like AlignmentType::EndsFree's fields."""
+    m, o, e = costs
+    B = engine.Bound
+    conv = lambda b: B.Unbounded if b[0] == 0 else (B.Included(b[1]) if b[0] == 1 else B.Excluded(b[1]))
+    names = ("qry_free_begin", "qry_free_end", "graph_free_begin", "graph_free_end")
+    at = engine.AlignmentType.EndsFree(**{k: conv(bounds.get(k, (0, 0))) for k in names})
+    al = engine.PoastaAligner(getattr(engine, cfg_cls)(engine.GapAffine(m, e, o)), aln_type=at, queue_entries_per_cell=4.0)
+    qseq, qoff = pack_queries(qs)
+    res = al.align_batch(g, qseq=qseq, qoff=qoff, pruning=pruning)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    heur = oracle.H_MINGAP if cfg_cls == "AffineMinGapCost" else oracle.H_DIJKSTRA
+    spec = oracle.ends_free(*[bounds.get(k, (0, 0)) if bounds.get(k, (0, 0))[0] else 0 for k in names])
+    n = 0
+    with oracle.alignment_type(spec):
+        A = og.astar_batch(qseq, qoff, oracle.Costs(*costs), heur, pruning, threads=2)
+    for i in range(len(qs)):
+        if A["status"][i] != 0:
+            assert int(res.flags[i]) & 4, "reference panics: REF_PANIC expected (query %d)" % i
+            continue
+        assert int(res.flags[i]) & ~0x10 == 0, "flags, query %d" % i     # TRUNCATED: does not begin at the start node
+        assert int(res.score[i]) == int(A["score"][i]), "score, query %d" % i
+        assert res.raw_alignment(i) == oracle.batch_alignment(A, i), "alignment, query %d" % i
+        n += 1
+    return n
+
+
+@pytest.mark.gpu
+def test_gpu_ends_free_matches_the_literal_search(engine, oracle):
+    """AlignmentType::EndsFree through the C ABI (the replay is implied): scores and alignments equal the oracle's
+    literal restatement, which the reference's own ends-free known answers pin (tests/test_oracle_kat.py)."""
+    INC, EXC = 1, 2
+    spans = [dict(), dict(graph_free_begin=(INC, 0)), dict(qry_free_end=(INC, 2)), dict(qry_free_end=(EXC, 3), graph_free_end=(INC, 2)),
+             dict(graph_free_begin=(INC, 0), qry_free_end=(INC, 0), graph_free_end=(EXC, 3)), dict(graph_free_end=(INC, 0))]
+    n = 0
+    for seed in range(36):
+        rng = np.random.Generator(np.random.PCG64(5000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, 0.3, alpha) for _ in range(12)]
+        costs = [(4, 6, 2), (2, 8, 1), (1, 10, 2), (3, 1, 1)][seed % 4]
+        cfg = "AffineMinGapCost" if seed % 3 else "AffineDijkstra"
+        n += _gpu_ends_free_vs_astar(engine, oracle, g, qs, costs, cfg, seed % 5 != 0, spans[seed % len(spans)])
+    assert n > 300
+    # the reference's own fixtures (gap_affine.rs:1124-1182, :1320-1352; edge_cases.rs:64-112, :225-262)
+    b = GraphBuilder(); b.add_path(np.frombuffer(b"ATCG", np.uint8)); g = b.finish()
+    al = engine.PoastaAligner(engine.AffineDijkstra(engine.GapAffine(1, 2, 8)), aln_type=engine.AlignmentType.EndsFree())
+    r = al.align_batch(g, [b"TCG", b"ATCGAA", b""])
+    assert r.score.tolist() == [0, 0, 0]
+    b = GraphBuilder(); b.add_path(np.frombuffer(b"AAAA", np.uint8)); g = b.finish()
+    al = engine.PoastaAligner(engine.AffineDijkstra(engine.GapAffine(2, 1, 8)), aln_type=engine.AlignmentType.EndsFree())
+    r = al.align_batch(g, [b"TTTT"])
+    assert int(r.score[0]) == 2 and r.raw_alignment(0) == []          # "chose not to align (cost 2)", edge_cases.rs:100-108
+    b = GraphBuilder(); b.add_path(np.frombuffer(b"A", np.uint8)); g = b.finish()
+    al = engine.PoastaAligner(engine.AffineDijkstra(engine.GapAffine(1, 2, 8)), aln_type=engine.AlignmentType.EndsFree())
+    r = al.align_batch(g, [b"A", b"T"])
+    assert int(r.score[0]) == 0 and int(r.score[1]) == 10 and r.raw_alignment(1) == [(0xFFFFFFFF, 0)]   # edge_cases.rs:246-256
 
 
 @pytest.mark.gpu
