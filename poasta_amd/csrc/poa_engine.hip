@@ -18,6 +18,7 @@
 #include "poa_exact_kernel.hpp"
 #include "poa_kernels.hpp"
 #include "poa_forward_packed.hpp"
+#include "poa_forward_px.hpp"
 
 using namespace poa_amd;
 
@@ -456,7 +457,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         tp.score = b->d_score.p; tp.flags = b->d_flags.p; tp.n_pairs = b->d_npairs.p;
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
         tp.spec_depth = spec_depth;
-        tp.exact_pass = 0; tp.ex_status = nullptr; tp.ex_end = nullptr;
+        tp.exact_pass = 0; tp.ex_status = nullptr; tp.ex_end = nullptr; tp.code_fmt = 0;
         FwdParams fp;
         fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
         fp.first_query = ch.first; fp.n_queries = ch.count;
@@ -479,7 +480,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 // queries longer than one strip: one workgroup per query, its strips pipelined over the waves (MW)
                 bool mw = max_pitch > 512 * quads;
                 if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
-                if (mw) {
+                bool px = !mw && quads == 2 && !fuse_tb;  // one strip of up to 1024 columns: the pairs-across-quads kernel
+                if (const char* xv = getenv("POA_PX")) px = px && atoi(xv) != 0;
+                if (px) {
+                    tp.code_fmt = 1;
+                    hipLaunchKernelGGL(poa_forward_px_kernel, dim3(blocks), dim3(256), 0, stream, fp);
+                } else if (mw) {
                     // narrow strips (more waves) until the chunk alone fills the chip
                     if (!quads_override) quads = ((uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192) ? 2 : 1;
                     const uint32_t strips = (max_pitch + 512 * quads - 1) / (512 * quads);

@@ -1,0 +1,217 @@
+// Packed-u16 forward kernel, "pairs across quads" register mapping (gfx950) — the default for queries of
+// 512 < pitch <= 1024 columns (one strip), i.e. the headline workload.
+//
+// Same recurrences and the same compact plane layout as poa_forward_packed_kernel<2> (M plane u16, D rows
+// where ROW_STORE_D, 4 flag bits per cell), but the two 16-bit halves of a VGPR no longer hold ADJACENT
+// columns: lane l owns columns 8l..8l+7 of quad 0 and 512+8l..512+8l+7 of quad 1, and register k holds
+//      lo half = column 8l + k (quad 0),   hi half = column 512 + 8l + k (quad 1).
+// Consequences (456 -> ~330 VALU instructions per 1024-cell row):
+//   * "the column to the left" of register k is register k-1 — no v_alignbit shifts; only k = 0 needs the
+//     neighbour lane (one DPP wave_shr:1 serves both quads, lane 0's hi half = lane 63's lo half);
+//   * the in-lane insertion chain is a plain packed recurrence over k (2 instructions per register instead of 7),
+//     both quads advancing together, and ONE packed DPP scan replaces the two per-quad scans;
+//   * stores/loads repack with v_perm_b32 (one per dword), the only new cost.
+// Flag bits are kept as bit-planes: per 8 columns one dword = [A bits | B bits | C bits | D bits], bit k of a byte =
+// column k (TbParams::code_fmt = 1; the nibble format of the other kernels is code_fmt 0).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "poa_forward_packed.hpp"
+
+namespace poa_amd {
+
+// inclusive min-plus scan over the lanes on both halves at once; the *_2 constants are packed per-lane weights
+__device__ __forceinline__ uint32_t wave_scan_min_plus_pk(uint32_t t, uint32_t step2, uint32_t w15_2, uint32_t w31_2) {
+    constexpr uint32_t INF2 = 0xFFFFFFFFu;
+    uint32_t P = t;
+    P = pk_min(P, pk_add_sat((uint32_t)__builtin_amdgcn_update_dpp((int)INF2, (int)P, 0x111, 0xF, 0xF, false), step2));
+    P = pk_min(P, pk_add_sat((uint32_t)__builtin_amdgcn_update_dpp((int)INF2, (int)P, 0x112, 0xF, 0xF, false), 2 * step2));
+    P = pk_min(P, pk_add_sat((uint32_t)__builtin_amdgcn_update_dpp((int)INF2, (int)P, 0x114, 0xF, 0xF, false), 4 * step2));
+    P = pk_min(P, pk_add_sat((uint32_t)__builtin_amdgcn_update_dpp((int)INF2, (int)P, 0x118, 0xF, 0xF, false), 8 * step2));
+    P = pk_min(P, pk_add_sat((uint32_t)__builtin_amdgcn_update_dpp((int)INF2, (int)P, 0x142, 0xA, 0xF, false), w15_2));
+    P = pk_min(P, pk_add_sat((uint32_t)__builtin_amdgcn_update_dpp((int)INF2, (int)P, 0x143, 0xC, 0xF, false), w31_2));
+    return P;
+}
+
+// {a.lo, b.lo} -> (a.lo | b.lo << 16);  {a.hi, b.hi} -> (a.hi | b.hi << 16)
+__device__ __forceinline__ uint32_t pk_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pk_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
+    constexpr int K = 8;                 // columns per lane and quad == packed registers per row array
+    constexpr uint32_t QW = 64 * K;      // 512 columns per quad
+    constexpr uint32_t I16 = 0xFFFFu, INF2 = 0xFFFFFFFFu;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    if (wq >= P.n_queries) return;
+    const uint32_t qi = P.first_query + wq;
+    const uint64_t qbeg = P.qoff[qi];
+    const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
+    const uint8_t* __restrict__ q = P.qseq + qbeg;
+    const uint32_t pitch = P.pitch[qi];  // <= 1024 (launcher: one strip)
+    const uint64_t RP = (uint64_t)P.n_rows * pitch;
+    uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
+    uint16_t* __restrict__ Ip = Mp + RP;  // holds the flag bit-planes
+    uint16_t* __restrict__ Dp = Ip + RP;
+    const uint32_t e = P.cost_e, oe = P.cost_oe, x = P.cost_x;
+    const uint32_t e2 = e | (e << 16), oe2 = oe | (oe << 16), x2 = x | (x << 16);
+    auto pack16 = [](uint32_t v) { v = v < I16 ? v : I16; return v | (v << 16); };
+    const uint32_t step = K * e;
+    const uint32_t step2 = pack16(step);
+    const uint32_t w15_2 = pack16(((lane & 15u) + 1u) * step);
+    const uint32_t w31_2 = pack16(lane >= 32u ? (lane - 31u) * step : 0u);  // only lanes >= 32 receive the row_bcast:31 value
+    const uint32_t lane_off2 = pack16(K * lane * e);
+    const uint32_t c_lo = K * lane, c_hi = QW + K * lane;
+    const bool act_lo = c_lo < pitch, act_hi = c_hi < pitch;  // my 8 columns of the quad lie inside the plane row
+    uint32_t qP[K];                     // my query symbols: lo = q[c_lo + k], hi = q[c_hi + k] (0 past the end: never a symbol)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t a = (c_lo + k < L) ? (uint32_t)q[c_lo + k] : 0u, b = (c_hi + k < L) ? (uint32_t)q[c_hi + k] : 0u;
+        qP[k] = a | (b << 16);
+    }
+    // symbols left of my first columns
+    const uint32_t qlE = ((c_lo > 0 && c_lo - 1 < L) ? (uint32_t)q[c_lo - 1] : 0u) | (((c_hi - 1 < L) ? (uint32_t)q[c_hi - 1] : 0u) << 16);
+
+    uint32_t Mprev[K], Dprev[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { Mprev[k] = INF2; Dprev[k] = INF2; }
+
+    for (uint32_t r = 0; r < P.n_rows; ++r) {
+        const RowMeta meta = P.rows[r];
+        const uint32_t sym = meta.sym;
+        const uint32_t sym2 = sym | (sym << 16);
+        const uint64_t rbase = (uint64_t)r * pitch + K * lane;
+        uint32_t PMl = INF2;  // min over predecessors of M[p][my first column - 1], both quads
+
+        // lane l <- v of lane l-1; lane 0: lo half <- INF (no column -1), hi half <- lane 63's lo half (column 511)
+        auto shr_lane = [&](uint32_t v) {
+            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            return pk_wave_shr1(v, I16 | (last << 16));
+        };
+
+        auto row_body = [&](const uint32_t (&PM)[K], const uint32_t (&PD)[K]) {
+            uint32_t Mc[K], Ic[K], Dc[K], PDe[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], e2);
+            if (meta.flags & ROW_END) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    Dc[k] = PDe[k];
+                    Mc[k] = pk_min(PM[k], Dc[k]);
+                    Ic[k] = INF2;
+                }
+            } else {
+                // insertion-open rule, branch-free: "always" == the child symbol 0, which no query symbol equals
+                const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
+                const uint32_t csym2 = cs1 | (cs1 << 16);
+                const uint32_t start_keep = ((meta.flags & ROW_START) && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                uint32_t Hc[K];
+                uint32_t pm_left = PMl;
+                // (mis)match cost of the column to the left: x where its symbol differs (x - (eq << 8) saturates to 0 on a match)
+                uint32_t cost_left = pk_sub_sat(x2, pk_shl<8>(pk_is_zero(qlE ^ sym2)));
+                uint32_t t = INF2;  // in-lane insertion chain, both quads at once
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t eq1 = pk_is_zero(qP[k] ^ sym2);  // 1 where the query symbol equals the row's symbol
+                    // D: open a deletion only where the symbols differ (or past the query end, where q is 0)
+                    Dc[k] = pk_min(PDe[k], pk_inf_where(pk_add_sat(PM[k], oe2), eq1));
+                    Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
+                    if (k == 0) Hc[k] &= start_keep;  // H[start][0] = 0
+                    pm_left = PM[k];
+                    cost_left = pk_sub_sat(x2, pk_shl<8>(eq1));
+                    // insertion open: A = (q != child symbol) ? H + oe : INF
+                    const uint32_t a = pk_inf_where(pk_add_sat(Hc[k], oe2), pk_is_zero(qP[k] ^ csym2));
+                    Ic[k] = t;
+                    t = pk_min(pk_add_sat(t, e2), a);
+                }
+                const uint32_t Pm = wave_scan_min_plus_pk(t, step2, w15_2, w31_2);
+                const uint32_t excl = pk_wave_shr1(Pm, INF2);
+                // carry entering quad 1 = everything that leaves quad 0 (nothing enters quad 0: single strip)
+                const uint32_t total_lo = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63) & 0xFFFFu;
+                const uint32_t cin = pk_min(excl, pk_add_sat(I16 | (total_lo << 16), lane_off2));
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    Ic[k] = pk_min(Ic[k], pk_add_sat(cin, (uint32_t)k * e2));
+                    Mc[k] = pk_min(Hc[k], Ic[k]);
+                }
+            }
+
+            // flag bit-planes: A: I == M, B: I[j] == I[j-1] + e, C: D == M, D: D == PD + e  (lhs >= rhs by construction)
+            uint32_t i_left = shr_lane(Ic[K - 1]);
+            uint32_t accA = 0, accB = 0, accC = 0, accD = 0;  // bit k (quad 0) and bit 16 + k (quad 1)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                accA |= pk_eq_ge(Ic[k], Mc[k]) << k;
+                accB |= pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]) << k;
+                accC |= pk_eq_ge(Dc[k], Mc[k]) << k;
+                accD |= pk_eq_ge(PDe[k], Dc[k]) << k;
+                i_left = Ic[k];
+            }
+            const uint32_t ab = __builtin_amdgcn_perm(accB, accA, 0x06020400u);  // [A.q0, B.q0, A.q1, B.q1]
+            const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);  // [C.q0, D.q0, C.q1, D.q1]
+            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + lane;
+            const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+            if (act_lo) {
+                *reinterpret_cast<uint4*>(Mp + rbase) =
+                    make_uint4(pk_lo_lo(Mc[0], Mc[1]), pk_lo_lo(Mc[2], Mc[3]), pk_lo_lo(Mc[4], Mc[5]), pk_lo_lo(Mc[6], Mc[7]));
+                codes[0] = pk_lo_lo(ab, cd);
+                if (keep_d)
+                    *reinterpret_cast<uint4*>(Dp + rbase) =
+                        make_uint4(pk_lo_lo(Dc[0], Dc[1]), pk_lo_lo(Dc[2], Dc[3]), pk_lo_lo(Dc[4], Dc[5]), pk_lo_lo(Dc[6], Dc[7]));
+            }
+            if (act_hi) {
+                *reinterpret_cast<uint4*>(Mp + rbase + QW) =
+                    make_uint4(pk_hi_hi(Mc[0], Mc[1]), pk_hi_hi(Mc[2], Mc[3]), pk_hi_hi(Mc[4], Mc[5]), pk_hi_hi(Mc[6], Mc[7]));
+                codes[QW / 8] = pk_hi_hi(ab, cd);
+                if (keep_d)
+                    *reinterpret_cast<uint4*>(Dp + rbase + QW) =
+                        make_uint4(pk_hi_hi(Dc[0], Dc[1]), pk_hi_hi(Dc[2], Dc[3]), pk_hi_hi(Dc[4], Dc[5]), pk_hi_hi(Dc[6], Dc[7]));
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) { Mprev[k] = Mc[k]; Dprev[k] = Dc[k]; }
+        };
+
+        if (meta.flags & ROW_CHAIN) {
+            PMl = shr_lane(Mprev[K - 1]);
+            row_body(Mprev, Dprev);
+        } else {
+            uint32_t PM[K], PD[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { PM[k] = INF2; PD[k] = INF2; }
+            if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // I read back rows this wave stored
+            for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
+                const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
+                uint32_t tm[K], td[K];
+                if (pr + 1 == r) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
+                } else {
+                    const uint64_t pbase = (uint64_t)pr * pitch + K * lane;
+                    uint4 m0 = make_uint4(INF2, INF2, INF2, INF2), d0 = m0, m1 = m0, d1 = m0;
+                    if (act_lo) {
+                        m0 = *reinterpret_cast<const uint4*>(Mp + pbase);
+                        d0 = *reinterpret_cast<const uint4*>(Dp + pbase);
+                    }
+                    if (act_hi) {
+                        m1 = *reinterpret_cast<const uint4*>(Mp + pbase + QW);
+                        d1 = *reinterpret_cast<const uint4*>(Dp + pbase + QW);
+                    }
+                    const uint32_t a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
+                    const uint32_t b0[4] = {d0.x, d0.y, d0.z, d0.w}, b1[4] = {d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        tm[2 * i] = pk_lo_lo(a0[i], a1[i]); tm[2 * i + 1] = pk_hi_hi(a0[i], a1[i]);
+                        td[2 * i] = pk_lo_lo(b0[i], b1[i]); td[2 * i + 1] = pk_hi_hi(b0[i], b1[i]);
+                    }
+                }
+                PMl = pk_min(PMl, shr_lane(tm[K - 1]));
+#pragma unroll
+                for (int k = 0; k < K; ++k) { PM[k] = pk_min(PM[k], tm[k]); PD[k] = pk_min(PD[k], td[k]); }
+            }
+            row_body(PM, PD);
+        }
+    }
+}
+
+}  // namespace poa_amd

@@ -74,6 +74,7 @@ struct TbParams {
     uint32_t exact_pass;
     const uint32_t* ex_status;    // [total] 0 ok, 1 reference panic, 2 workspace overflow, 0xFFFFFFFF not replayed
     const uint32_t* ex_end;       // [2 * total] (row, offset) of the end cell the replayed search stopped at
+    uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel)
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -152,7 +153,8 @@ struct TbCtx {
     const T* M;
     const T* I;
     const T* D;
-    const uint32_t* codes;  // compact layout: nibble per cell at the I plane's place
+    const uint32_t* codes;  // compact layout: 4 flag bits per cell at the I plane's place
+    uint32_t code_fmt;      // 0: nibble per cell, 1: bit-planes
     const uint8_t* q;
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
@@ -181,7 +183,12 @@ template <typename T>
 __device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uint32_t j) {
     // 8 cells per dword; the nibble of column k = j & 7 sits at position (k >> 1) + 4 * (k & 1)
     const uint32_t k = j & 7u;
-    return (c.codes[(uint64_t)row * (c.pitch / 8) + (j >> 3)] >> (4 * ((k >> 1) + 4 * (k & 1)))) & 0xFu;
+    const uint32_t w = c.codes[(uint64_t)row * (c.pitch / 8) + (j >> 3)];
+    if (c.code_fmt == 1) {  // bit-planes: byte b holds flag bit b of the 8 cells, bit k = column k
+        const uint32_t v = w >> k;
+        return (v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u);
+    }
+    return (w >> (4 * ((k >> 1) + 4 * (k & 1)))) & 0xFu;
 }
 // gap_cs: the score of the current D / I cell, carried along the walk (compact layout has no I plane and
 // only some D rows; with full planes it equals the stored value and the stored value is used).
@@ -291,6 +298,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     c.I = c.M + RP;
     c.D = c.I + RP;
     c.codes = reinterpret_cast<const uint32_t*>(c.I);
+    c.code_fmt = P.code_fmt;
     c.start_row = P.start_row; c.end_row = P.end_row;
     c.x = P.cost_x; c.o = P.cost_o; c.e = P.cost_e;
     const uint32_t L = c.L;
