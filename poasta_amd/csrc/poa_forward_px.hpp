@@ -21,6 +21,11 @@
 
 namespace poa_amd {
 
+typedef uint32_t poa_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const poa_u32x4 CRowWords;  // a RowMeta as four dwords, constant address space
+static_assert(sizeof(RowMeta) == 16, "RowMeta is read as one 16-byte scalar load");
+typedef __attribute__((address_space(4))) const uint32_t CU32;
+
 // inclusive min-plus scan over the lanes on both halves at once; the *_2 constants are packed per-lane weights
 __device__ __forceinline__ uint32_t wave_scan_min_plus_pk(uint32_t t, uint32_t step2, uint32_t w15_2, uint32_t w31_2) {
     constexpr uint32_t INF2 = 0xFFFFFFFFu;
@@ -73,12 +78,38 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     // symbols left of my first columns
     const uint32_t qlE = ((c_lo > 0 && c_lo - 1 < L) ? (uint32_t)q[c_lo - 1] : 0u) | (((c_hi - 1 < L) ? (uint32_t)q[c_hi - 1] : 0u) << 16);
 
-    uint32_t Mprev[K], Dprev[K];
+    // Symbol masks per lane, staged once in LDS: mask[s][k] = 0xFFFF per half where my query symbol equals symbol s
+    // ("ACGT"[s]; s = 4: no symbol, all zero).  A row then fetches the masks of its symbol and of its child symbol
+    // (4 ds_read_b128) instead of recomputing them (7 VALU instructions per register).  Other symbols: computed.
+    __shared__ uint4 sym_tab[4 * 5 * 2 * 64];
+    uint4* my_tab = sym_tab + (threadIdx.x >> 6) * (5 * 2 * 64) + lane;
+    {
+        const uint32_t letters[4] = {'A', 'C', 'G', 'T'};
 #pragma unroll
-    for (int k = 0; k < K; ++k) { Mprev[k] = INF2; Dprev[k] = INF2; }
+        for (int si = 0; si < 4; ++si) {
+            const uint32_t s2 = letters[si] | (letters[si] << 16);
+            uint32_t m[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) m[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ s2)));
+            my_tab[(si * 2 + 0) * 64] = make_uint4(m[0], m[1], m[2], m[3]);
+            my_tab[(si * 2 + 1) * 64] = make_uint4(m[4], m[5], m[6], m[7]);
+        }
+        my_tab[(4 * 2 + 0) * 64] = make_uint4(0, 0, 0, 0);
+        my_tab[(4 * 2 + 1) * 64] = make_uint4(0, 0, 0, 0);
+        // each lane reads back only what it wrote itself: no barrier needed
+    }
 
-    for (uint32_t r = 0; r < P.n_rows; ++r) {
-        const RowMeta meta = P.rows[r];
+    // The graph tables are read-only for the whole launch: read them through the constant address space so that
+    // they come in over the scalar cache (s_load).  As a plain global load the row record is a VECTOR load, and
+    // waiting for it (vmcnt) also waits for every plane store of the previous row.
+    const CRowWords* crows = (const CRowWords*)P.rows;
+    const CU32* cpred = (const CU32*)P.pred_rows;
+
+    // one row: reads the previous row from (Mprev, Dprev), leaves this row in (Mout, Dout) — the caller alternates two
+    // register sets so that no row ends with 16 register copies
+    auto do_row = [&](const uint32_t r, const uint32_t (&Mprev)[K], const uint32_t (&Dprev)[K], uint32_t (&Mout)[K], uint32_t (&Dout)[K]) {
+        const poa_u32x4 mw = crows[r];  // {node, pred_begin, pred_count, sym | child_sym << 8 | flags << 16 | sym_idx << 24}
+        struct { uint32_t pred_begin, pred_count, sym, child_sym, flags, sym_idx; } meta{mw.y, mw.z, mw.w & 0xFFu, (mw.w >> 8) & 0xFFu, (mw.w >> 16) & 0xFFu, mw.w >> 24};
         const uint32_t sym = meta.sym;
         const uint32_t sym2 = sym | (sym << 16);
         const uint64_t rbase = (uint64_t)r * pitch + K * lane;
@@ -91,7 +122,9 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
         };
 
         auto row_body = [&](const uint32_t (&PM)[K], const uint32_t (&PD)[K]) {
-            uint32_t Mc[K], Ic[K], Dc[K], PDe[K];
+            uint32_t (&Mc)[K] = Mout;
+            uint32_t (&Dc)[K] = Dout;
+            uint32_t Ic[K], PDe[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], e2);
             if (meta.flags & ROW_END) {
@@ -104,24 +137,40 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             } else {
                 // insertion-open rule, branch-free: "always" == the child symbol 0, which no query symbol equals
                 const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
-                const uint32_t csym2 = cs1 | (cs1 << 16);
                 const uint32_t start_keep = ((meta.flags & ROW_START) && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                // masks (0xFFFF per half): mD where my query symbol equals the row's symbol, mI where it equals the child symbol
+                uint32_t mD[K], mI[K];
+                const uint32_t si = meta.sym_idx & 15u, ci = meta.sym_idx >> 4;  // set by build_flat_graph
+                if (si < 4) {
+                    const uint4 a = my_tab[(si * 2 + 0) * 64], b = my_tab[(si * 2 + 1) * 64];
+                    mD[0] = a.x; mD[1] = a.y; mD[2] = a.z; mD[3] = a.w; mD[4] = b.x; mD[5] = b.y; mD[6] = b.z; mD[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) mD[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ sym2)));
+                }
+                if (ci < 5) {
+                    const uint4 a = my_tab[(ci * 2 + 0) * 64], b = my_tab[(ci * 2 + 1) * 64];
+                    mI[0] = a.x; mI[1] = a.y; mI[2] = a.z; mI[3] = a.w; mI[4] = b.x; mI[5] = b.y; mI[6] = b.z; mI[7] = b.w;
+                } else {
+                    const uint32_t csym2 = cs1 | (cs1 << 16);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) mI[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ csym2)));
+                }
                 uint32_t Hc[K];
                 uint32_t pm_left = PMl;
-                // (mis)match cost of the column to the left: x where its symbol differs (x - (eq << 8) saturates to 0 on a match)
-                uint32_t cost_left = pk_sub_sat(x2, pk_shl<8>(pk_is_zero(qlE ^ sym2)));
+                // (mis)match cost of the column to the left: x where its symbol differs, 0 on a match (x -sat 0xFFFF)
+                uint32_t cost_left = pk_sub_sat(x2, pku(pkv(0u) - pkv(pk_is_zero(qlE ^ sym2))));
                 uint32_t t = INF2;  // in-lane insertion chain, both quads at once
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t eq1 = pk_is_zero(qP[k] ^ sym2);  // 1 where the query symbol equals the row's symbol
                     // D: open a deletion only where the symbols differ (or past the query end, where q is 0)
-                    Dc[k] = pk_min(PDe[k], pk_inf_where(pk_add_sat(PM[k], oe2), eq1));
+                    Dc[k] = pk_min(PDe[k], pk_max(pk_add_sat(PM[k], oe2), mD[k]));
                     Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
                     if (k == 0) Hc[k] &= start_keep;  // H[start][0] = 0
                     pm_left = PM[k];
-                    cost_left = pk_sub_sat(x2, pk_shl<8>(eq1));
+                    cost_left = pk_sub_sat(x2, mD[k]);
                     // insertion open: A = (q != child symbol) ? H + oe : INF
-                    const uint32_t a = pk_inf_where(pk_add_sat(Hc[k], oe2), pk_is_zero(qP[k] ^ csym2));
+                    const uint32_t a = pk_max(pk_add_sat(Hc[k], oe2), mI[k]);
                     Ic[k] = t;
                     t = pk_min(pk_add_sat(t, e2), a);
                 }
@@ -168,8 +217,6 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     *reinterpret_cast<uint4*>(Dp + rbase + QW) =
                         make_uint4(pk_hi_hi(Dc[0], Dc[1]), pk_hi_hi(Dc[2], Dc[3]), pk_hi_hi(Dc[4], Dc[5]), pk_hi_hi(Dc[6], Dc[7]));
             }
-#pragma unroll
-            for (int k = 0; k < K; ++k) { Mprev[k] = Mc[k]; Dprev[k] = Dc[k]; }
         };
 
         if (meta.flags & ROW_CHAIN) {
@@ -181,7 +228,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             for (int k = 0; k < K; ++k) { PM[k] = INF2; PD[k] = INF2; }
             if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // I read back rows this wave stored
             for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
-                const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
+                const uint32_t pr = cpred[meta.pred_begin + pe];
                 uint32_t tm[K], td[K];
                 if (pr + 1 == r) {
 #pragma unroll
@@ -211,7 +258,17 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             }
             row_body(PM, PD);
         }
+    };
+
+    uint32_t MA[K], DA[K], MB[K], DB[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { MA[k] = INF2; DA[k] = INF2; }
+    uint32_t r = 0;
+    for (; r + 1 < P.n_rows; r += 2) {
+        do_row(r, MA, DA, MB, DB);
+        do_row(r + 1, MB, DB, MA, DA);
     }
+    if (r < P.n_rows) do_row(r, MA, DA, MB, DB);
 }
 
 }  // namespace poa_amd

@@ -29,7 +29,7 @@ struct RowMeta {  // 16 bytes, one per row
     uint8_t sym;
     uint8_t child_sym;    // common symbol of the non-end children (valid unless ALWAYS/NEVER)
     uint8_t flags;
-    uint8_t pad;
+    uint8_t sym_idx;      // low nibble: index of sym in "ACGT" (5: other); high nibble: same for child_sym (4: none / open always)
 };
 static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
 
