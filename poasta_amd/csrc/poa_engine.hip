@@ -483,8 +483,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 bool px = !mw && quads == 2 && !fuse_tb;  // one strip of up to 1024 columns: the pairs-across-quads kernel
                 if (const char* xv = getenv("POA_PX")) px = px && atoi(xv) != 0;
                 if (px) {
-                    tp.code_fmt = 1;
-                    hipLaunchKernelGGL(poa_forward_px_kernel, dim3(blocks), dim3(256), 0, stream, fp);
+                    // scores below 0x3FFF (same bound as for u16, one power lower): two flags ride in the stored M value
+                    bool mf = ub <= 16382;
+                    if (const char* fv2 = getenv("POA_MF")) mf = mf && atoi(fv2) != 0;
+                    tp.code_fmt = mf ? 2u : 1u;
+                    if (mf) hipLaunchKernelGGL(poa_forward_px_kernel<true>, dim3(blocks), dim3(256), 0, stream, fp);
+                    else hipLaunchKernelGGL(poa_forward_px_kernel<false>, dim3(blocks), dim3(256), 0, stream, fp);
                 } else if (mw) {
                     // narrow strips (more waves) until the chunk alone fills the chip
                     if (!quads_override) quads = ((uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192) ? 2 : 1;

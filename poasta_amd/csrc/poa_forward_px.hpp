@@ -43,6 +43,11 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus_pk(uint32_t t, uint32_t s
 __device__ __forceinline__ uint32_t pk_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 __device__ __forceinline__ uint32_t pk_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// MF (needs every relevant score < 0x3FFF, decided by the launcher from the bound on the optimal score): the two flags a
+// Match-state traceback step reads — I == M, D == M — are stored in bits 14 and 15 of the M value itself (0x3FFF = INF,
+// larger finite values of irrelevant cells are clamped to it), and the flag plane keeps only the two gap-state flags
+// (one dword per lane and row).  The traceback then needs ONE load per diagonal step instead of two.
+template <bool MF>
 __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     constexpr int K = 8;                 // columns per lane and quad == packed registers per row array
     constexpr uint32_t QW = 64 * K;      // 512 columns per quad
@@ -189,30 +194,38 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             // flag bit-planes: A: I == M, B: I[j] == I[j-1] + e, C: D == M, D: D == PD + e  (lhs >= rhs by construction)
             uint32_t i_left = shr_lane(Ic[K - 1]);
             uint32_t accA = 0, accB = 0, accC = 0, accD = 0;  // bit k (quad 0) and bit 16 + k (quad 1)
+            uint32_t Ms[K];                                   // what is stored for M
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                accA |= pk_eq_ge(Ic[k], Mc[k]) << k;
+                const uint32_t fA = pk_eq_ge(Ic[k], Mc[k]), fC = pk_eq_ge(Dc[k], Mc[k]);
+                if (MF) {
+                    Ms[k] = (fC << 15) | ((fA << 14) | pk_min(Mc[k], 0x3FFF3FFFu));
+                } else {
+                    Ms[k] = Mc[k];
+                    accA |= fA << k;
+                    accC |= fC << k;
+                }
                 accB |= pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]) << k;
-                accC |= pk_eq_ge(Dc[k], Mc[k]) << k;
                 accD |= pk_eq_ge(PDe[k], Dc[k]) << k;
                 i_left = Ic[k];
             }
             const uint32_t ab = __builtin_amdgcn_perm(accB, accA, 0x06020400u);  // [A.q0, B.q0, A.q1, B.q1]
             const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);  // [C.q0, D.q0, C.q1, D.q1]
-            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + lane;
+            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (MF ? (uint64_t)r * 64u : (uint64_t)r * (pitch / 8)) + lane;
             const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
             if (act_lo) {
                 *reinterpret_cast<uint4*>(Mp + rbase) =
-                    make_uint4(pk_lo_lo(Mc[0], Mc[1]), pk_lo_lo(Mc[2], Mc[3]), pk_lo_lo(Mc[4], Mc[5]), pk_lo_lo(Mc[6], Mc[7]));
-                codes[0] = pk_lo_lo(ab, cd);
+                    make_uint4(pk_lo_lo(Ms[0], Ms[1]), pk_lo_lo(Ms[2], Ms[3]), pk_lo_lo(Ms[4], Ms[5]), pk_lo_lo(Ms[6], Ms[7]));
+                if (MF) codes[0] = __builtin_amdgcn_perm(accD, accB, 0x06020400u);  // [B.q0, D.q0, B.q1, D.q1]
+                else codes[0] = pk_lo_lo(ab, cd);
                 if (keep_d)
                     *reinterpret_cast<uint4*>(Dp + rbase) =
                         make_uint4(pk_lo_lo(Dc[0], Dc[1]), pk_lo_lo(Dc[2], Dc[3]), pk_lo_lo(Dc[4], Dc[5]), pk_lo_lo(Dc[6], Dc[7]));
             }
             if (act_hi) {
                 *reinterpret_cast<uint4*>(Mp + rbase + QW) =
-                    make_uint4(pk_hi_hi(Mc[0], Mc[1]), pk_hi_hi(Mc[2], Mc[3]), pk_hi_hi(Mc[4], Mc[5]), pk_hi_hi(Mc[6], Mc[7]));
-                codes[QW / 8] = pk_hi_hi(ab, cd);
+                    make_uint4(pk_hi_hi(Ms[0], Ms[1]), pk_hi_hi(Ms[2], Ms[3]), pk_hi_hi(Ms[4], Ms[5]), pk_hi_hi(Ms[6], Ms[7]));
+                if (!MF) codes[QW / 8] = pk_hi_hi(ab, cd);
                 if (keep_d)
                     *reinterpret_cast<uint4*>(Dp + rbase + QW) =
                         make_uint4(pk_hi_hi(Dc[0], Dc[1]), pk_hi_hi(Dc[2], Dc[3]), pk_hi_hi(Dc[4], Dc[5]), pk_hi_hi(Dc[6], Dc[7]));
@@ -250,6 +263,15 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     for (int i = 0; i < 4; ++i) {
                         tm[2 * i] = pk_lo_lo(a0[i], a1[i]); tm[2 * i + 1] = pk_hi_hi(a0[i], a1[i]);
                         td[2 * i] = pk_lo_lo(b0[i], b1[i]); td[2 * i + 1] = pk_hi_hi(b0[i], b1[i]);
+                    }
+                    if (MF) {
+                        // strip the flags; the 14-bit INF becomes the 16-bit one again
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const uint32_t v = tm[k] & 0x3FFF3FFFu;
+                            const uint32_t is_inf = pku(pkv(0u) - pkv(pk_is_zero(v ^ 0x3FFF3FFFu)));  // 0xFFFF per half
+                            tm[k] = v | (is_inf & 0xC000C000u);
+                        }
                     }
                 }
                 PMl = pk_min(PMl, shr_lane(tm[K - 1]));

@@ -74,7 +74,8 @@ struct TbParams {
     uint32_t exact_pass;
     const uint32_t* ex_status;    // [total] 0 ok, 1 reference panic, 2 workspace overflow, 0xFFFFFFFF not replayed
     const uint32_t* ex_end;       // [2 * total] (row, offset) of the end cell the replayed search stopped at
-    uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel)
+    uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel<false>),
+                                  // 2 = flags A, C in bits 14, 15 of the stored M value, B, D as bit-planes (poa_forward_px_kernel<true>)
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -154,7 +155,7 @@ struct TbCtx {
     const T* I;
     const T* D;
     const uint32_t* codes;  // compact layout: 4 flag bits per cell at the I plane's place
-    uint32_t code_fmt;      // 0: nibble per cell, 1: bit-planes
+    uint32_t code_fmt;      // 0: nibble per cell, 1: bit-planes, 2: A, C in the M value + B, D bit-planes
     const uint8_t* q;
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
@@ -179,8 +180,23 @@ __device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j
     return (uint32_t)m.child_sym != (uint32_t)c.q[j];
 }
 
+// code_fmt 2: a stored M value carries two flags — bit 14: I == M, bit 15: D == M — over a 14-bit score (0x3FFF = INF)
+constexpr uint32_t MF_MASK = 0x3FFFu;
+__device__ __forceinline__ uint32_t mf_value(uint32_t raw) { const uint32_t v = raw & MF_MASK; return v == MF_MASK ? INF : v; }
+// the score of cell (row, j) of the M plane, whatever the format
+template <typename T>
+__device__ __forceinline__ uint32_t plM(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    if (c.code_fmt == 2) return mf_value((uint32_t)c.M[(uint64_t)row * c.pitch + j]);
+    return PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j);
+}
+
 template <typename T>
 __device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    if (c.code_fmt == 2) {  // one dword per lane and row: bytes [B quad 0, D quad 0, B quad 1, D quad 1], bit k = column 8l + k
+        const uint32_t w = c.codes[(uint64_t)row * 64u + ((j & 511u) >> 3)];
+        const uint32_t sh = (j >> 9) * 16u + (j & 7u);
+        return (((w >> sh) & 1u) << 1) | (((w >> (sh + 8u)) & 1u) << 3);
+    }
     // 8 cells per dword; the nibble of column k = j & 7 sits at position (k >> 1) + 4 * (k & 1)
     const uint32_t k = j & 7u;
     const uint32_t w = c.codes[(uint64_t)row * (c.pitch / 8) + (j >> 3)];
@@ -206,11 +222,18 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
     };
     if (st == 0) {
         // all loads of the step are issued before the first use (one memory round-trip for chain rows)
-        const uint32_t cs = pl(c.M, c.pitch, row, j);
-        uint32_t dv = 0, iv = 0, code = 0;
-        if (COMPACT) code = tb_code(c, row, j);
-        else { dv = pl(c.D, c.pitch, row, j); iv = pl(c.I, c.pitch, row, j); }
-        const uint32_t up = (row > 0 && j > 0) ? pl(c.M, c.pitch, row - 1, j - 1) : INF;  // the usual diagonal predecessor
+        uint32_t cs, dv = 0, iv = 0, code = 0;
+        if (COMPACT && c.code_fmt == 2) {
+            // the two flags a Match-state step needs travel with the score: no code load on the common path
+            const uint32_t raw = (uint32_t)c.M[(uint64_t)row * c.pitch + j];
+            cs = mf_value(raw);
+            code = ((raw >> 14) & 1u) | (((raw >> 15) & 1u) << 2);
+        } else {
+            cs = PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j);
+            if (COMPACT) code = tb_code(c, row, j);
+            else { dv = pl(c.D, c.pitch, row, j); iv = pl(c.I, c.pitch, row, j); }
+        }
+        const uint32_t up = (row > 0 && j > 0) ? plM(c, row - 1, j - 1) : INF;  // the usual diagonal predecessor
         first.cs = cs;
         if (cs == INF) return first;
         if (j > 0) {
@@ -223,7 +246,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
             } else {
                 for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
                     const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-                    if (pl(c.M, c.pitch, pr, pj) == target) cand(pr, pj, 0);
+                    if (plM(c, pr, pj) == target) cand(pr, pj, 0);
                 }
             }
         }
@@ -238,7 +261,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
         const bool real_open = !is_end && (j >= c.L || (uint32_t)m.sym != (uint32_t)c.q[j]);
         for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
             const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-            const uint32_t ps = pl(c.M, c.pitch, pr, j);
+            const uint32_t ps = plM(c, pr, j);
             if (ps == t_open) cand(pr, j, 0);
             else if (!real_open && ps < t_open) bad = true;  // phantom edge the reference does not re-check
         }
@@ -257,7 +280,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
         if (cs == INF) return first;
         if (j > 0) {
             const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
-            const uint32_t pm = pl(c.M, c.pitch, row, j - 1);
+            const uint32_t pm = plM(c, row, j - 1);
             if (pm == t_open) cand(row, j - 1, 0);
             else if (!tb_open_i(c, m, j - 1) && pm < t_open) bad = true;
             const bool ext = COMPACT ? (tb_code(c, row, j) & 2u) != 0 : pl(c.I, c.pitch, row, j - 1) == t_ext;
@@ -315,7 +338,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     // the cell the backtrace starts from: (end row, L) for Global; where the replayed search stopped for ends-free
     const uint32_t tb_row = (P.exact_pass && P.ex_end) ? P.ex_end[2 * qi] : c.end_row;
     const uint32_t tb_off = (P.exact_pass && P.ex_end) ? P.ex_end[2 * qi + 1] : L;
-    if (lane == 0) P.score[qi] = pl(c.M, c.pitch, tb_row, tb_off);
+    if (lane == 0) P.score[qi] = plM(c, tb_row, tb_off);
     const uint32_t end_node = c.rows[tb_row].node;
 
     bool done = false;
