@@ -440,8 +440,11 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         b->ran = true;
         return POA_OK;
     }
-    uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round)
+    uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round); measured best: 12 with 64-lane groups, 16 with 16
     if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
+    // lanes per traced query: 16 (four walks per wave) once there are more queries than wave slots, else 64
+    int tb_group = 16;
+    if (const char* gv = getenv("POA_TB_GROUP")) { const int v = atoi(gv); if (v == 16 || v == 64) tb_group = v; }
     bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
     if (const char* fv = getenv("POA_FUSE_TB")) fuse_tb = atoi(fv) != 0;
     int quads_override = 0;
@@ -531,7 +534,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
         if (!(fuse_tb && max_pitch <= 1024 && (!compact || packed))) {
-            if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            if (compact && tb_group == 16) {
+                TbParams tp16 = tp;
+                if (!getenv("POA_TB_DEPTH")) tp16.spec_depth = 16;
+                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 16>), dim3((ch.count + 15) / 16), dim3(256), 0, stream, tp16);
+            }
+            else if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             HIP_TRY(hipGetLastError());

@@ -300,8 +300,15 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
 // lanes whose step really is that diagonal move is accepted at once.  The first lane that deviates
 // (gap open/close, bubble predecessor, start reached) is then handled exactly like the sequential
 // rule, so the emitted alignment and flags are identical to a step-by-step walk.
-template <typename T, bool COMPACT>
+// GW lanes per query: 64 (one wave per query) or 16 (four queries per wave — the walk is a chain of dependent memory
+// round-trips, so what sets the throughput is how many walks are in flight; `lane` is the lane within the group).
+template <typename T, bool COMPACT, int GW = 64>
 __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t qi, const uint32_t lane) {
+    const uint32_t gbase = (threadIdx.x & 63u) - lane;  // first lane of my group within the wave
+    auto gballot = [&](bool pred) -> uint64_t {
+        const uint64_t b = __ballot(pred);
+        return GW == 64 ? b : ((b >> gbase) & ((1ull << (GW & 63)) - 1ull));
+    };
     if (P.exact_pass) {
         const uint32_t stt = P.ex_status[qi];
         if (stt != 0) {
@@ -333,7 +340,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     auto emit_at = [&](uint32_t pos, uint32_t rpos, uint32_t qpos) {
         if (pos < cap) out[cap - 1 - pos] = make_uint2(rpos, qpos);
     };
-    auto bc = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)src); };
+    auto bc = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)(gbase + src)); };
 
     // the cell the backtrace starts from: (end row, L) for Global; where the replayed search stopped for ends-free
     const uint32_t tb_row = (P.exact_pass && P.ex_end) ? P.ex_end[2 * qi] : c.end_row;
@@ -391,13 +398,14 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         // speculation: in Match state lane i assumes i (mis)matches into the previous row came before it, in Deletion
         // state i deletion-extensions into the previous row (long deletion runs: a read against a much longer graph)
         uint32_t depth = 1;
+        const uint32_t max_depth = P.spec_depth < (uint32_t)GW ? P.spec_depth : (uint32_t)GW;
         if (cst == 0) {
-            depth = P.spec_depth;
+            depth = max_depth;
             if (crow + 1 < depth) depth = crow + 1;
             if (cj + 1 < depth) depth = cj + 1;
         } else if (cst == 1) {
             // ramp up with the length of the run so far: most deletions are one or two rows long
-            depth = d_run < P.spec_depth ? (d_run ? d_run : 1u) : P.spec_depth;
+            depth = d_run < max_depth ? (d_run ? d_run : 1u) : max_depth;
             if (crow + 1 < depth) depth = crow + 1;
         }
         if (cst != 1) d_run = 0;
@@ -414,12 +422,12 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         // a "regular" step: (mis)match into exactly the cell the next lane speculated on, not yet at start
         const bool regular = active && bt.found && bt.row + 1 == my_row && bt.row != c.start_row &&
                              ((cst == 0 && bt.st == 0 && bt.j + 1 == my_j) || (cst == 1 && bt.st == 1 && bt.j == my_j));
-        const uint64_t rb = __ballot(regular);
+        const uint64_t rb = gballot(regular);
         const uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
         const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
-        if (__ballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
-        if (__ballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
-        if (__ballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
+        if (gballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
+        if (gballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
+        if (gballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
         if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, cst == 0 ? my_j - 1 : POA_NONE);
         cnt += p;
         if (p == depth) {
@@ -463,12 +471,12 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     }
 }
 
-template <typename T, bool COMPACT>
+template <typename T, bool COMPACT, int GW = 64>
 __global__ __launch_bounds__(256) void poa_traceback_kernel(TbParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform
+    const uint32_t lane = threadIdx.x & (uint32_t)(GW - 1);
+    const uint32_t wq = (blockIdx.x * blockDim.x + threadIdx.x) / (uint32_t)GW;  // uniform over the group
     if (wq >= P.n_queries) return;
-    traceback_wave<T, COMPACT>(P, P.first_query + wq, lane);
+    traceback_wave<T, COMPACT, GW>(P, P.first_query + wq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
