@@ -153,7 +153,7 @@ def main():
         elif os.environ.get("POA_COMPACT") == "0" or os.environ.get("POA_PACKED") == "0":
             kernel_name = "poa_forward_kernel<2, unsigned short>"
         else:
-            kernel_name = "poa_forward_packed_kernel<2>"
+            kernel_name = "poa_forward_px_kernel<true>" if os.environ.get("POA_PX") != "0" else "poa_forward_packed_kernel<2>"
         line = {
             "metric": "Gcells/sec (aligned bases/sec in config), gap-affine POA alignment, 1k-node POA x 10k x 1 kbp queries per GPU",
             "value": round(gcells, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
