@@ -444,7 +444,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
     // lanes per traced query: 16 (four walks per wave) once there are more queries than wave slots, else 64
     int tb_group = 16;
-    if (const char* gv = getenv("POA_TB_GROUP")) { const int v = atoi(gv); if (v == 16 || v == 64) tb_group = v; }
+    if (const char* gv = getenv("POA_TB_GROUP")) { const int v = atoi(gv); if (v == 8 || v == 16 || v == 32 || v == 64) tb_group = v; }
     bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
     if (const char* fv = getenv("POA_FUSE_TB")) fuse_tb = atoi(fv) != 0;
     int quads_override = 0;
@@ -538,6 +538,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 TbParams tp16 = tp;
                 if (!getenv("POA_TB_DEPTH")) tp16.spec_depth = 16;
                 hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 16>), dim3((ch.count + 15) / 16), dim3(256), 0, stream, tp16);
+            } else if (compact && tb_group == 32) {
+                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 32>), dim3((ch.count + 7) / 8), dim3(256), 0, stream, tp);
+            } else if (compact && tb_group == 8) {
+                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 8>), dim3((ch.count + 31) / 32), dim3(256), 0, stream, tp);
             }
             else if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
