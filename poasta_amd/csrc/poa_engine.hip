@@ -534,13 +534,15 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
         if (!(fuse_tb && max_pitch <= 1024 && (!compact || packed))) {
-            if (compact && tb_group == 16) {
+            // four walks per wave only when one walk per wave would exceed the chip's wave slots (256 CUs x 32)
+            const int tbg = (getenv("POA_TB_GROUP") || ch.count > 8192) ? tb_group : 64;
+            if (compact && tbg == 16) {
                 TbParams tp16 = tp;
                 if (!getenv("POA_TB_DEPTH")) tp16.spec_depth = 16;
                 hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 16>), dim3((ch.count + 15) / 16), dim3(256), 0, stream, tp16);
-            } else if (compact && tb_group == 32) {
+            } else if (compact && tbg == 32) {
                 hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 32>), dim3((ch.count + 7) / 8), dim3(256), 0, stream, tp);
-            } else if (compact && tb_group == 8) {
+            } else if (compact && tbg == 8) {
                 hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 8>), dim3((ch.count + 31) / 32), dim3(256), 0, stream, tp);
             }
             else if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
