@@ -158,13 +158,14 @@ def main():
             "metric": "Gcells/sec (aligned bases/sec in config), gap-affine POA alignment, 1k-node POA x 10k x 1 kbp queries per GPU",
             "value": round(gcells, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u32" if os.environ.get("POA_PLANES") == "32" else "u16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: synthetic 1000-node linear-ish POA graph (900 backbone + 50 SNP "
                                    "bubbles + 25 two-node insertion branches, seed 1), %d queries x %d bp per GPU (2%% sub, 1%% ins, "
                                    "1%% del, seed 2), Global, mismatch 4 / open 6 / extend 2" % (args.queries, args.length),
                        "rows": n_rows, "queries_per_gpu": args.queries, "query_len": args.length,
                        "cells_per_step": total_cells, "aligned_bases_per_sec": round(total_bases * args.steps / elapsed_max, 1),
                        "step": "forward planes + traceback + compaction, inputs and results resident in HBM",
+                       "arithmetic": "saturating packed u16 min-plus (exact: the optimal score is bounded by 3.8 k here; results are u32)",
                        "flagged_queries": flagged_total, "score_checksum": score_sum,
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                        "workload_gen_s": round(t_gen, 2), "plane_chunks": st["n_chunks"]},
