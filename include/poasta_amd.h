@@ -168,6 +168,9 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
                        const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
                        poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
                        uint32_t* flags, poa_stats_t* stats, int device);
+/* poa_align_batch parks its plane workspace (tens of GB; hipMalloc/hipFree of it cost seconds) per device for the next
+ * call; this returns that memory to the driver.  (src/bin/lasagna.rs has no counterpart: its tables live on the heap.) */
+void poa_release_cache(void);
 
 /* ---- resident batch (queries and results stay in HBM; used by the multi-GPU driver) ------ */
 /* poa_batch_create uploads graph + queries to `device` and sizes the score-plane workspace

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,58 @@ struct DevBuf {
 };
 }  // namespace
 
+// One cached plane workspace per device.  hipMalloc / hipFree of tens of GB cost seconds (measured: 0.8-6 s per
+// poa_align_batch on config 2 against 10 ms of kernels), and a host that calls poa_align_batch once per batch of reads
+// must not pay that every time: a released workspace is parked here and handed to the next batch on that device.
+struct PlaneWorkspace {
+    uint32_t* p = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    bool acquire(int dev, size_t need, std::string& err);
+    void release();
+    ~PlaneWorkspace() { release(); }
+};
+namespace {
+struct WsCache {
+    std::mutex mu;
+    void* p[16] = {};
+    size_t bytes[16] = {};
+} g_ws_cache;
+}  // namespace
+bool PlaneWorkspace::acquire(int dev, size_t need, std::string& err) {
+    release();
+    device = dev;
+    if (dev >= 0 && dev < 16) {
+        std::lock_guard<std::mutex> lk(g_ws_cache.mu);
+        if (g_ws_cache.p[dev] && g_ws_cache.bytes[dev] >= need) {
+            p = (uint32_t*)g_ws_cache.p[dev]; bytes = g_ws_cache.bytes[dev];
+            g_ws_cache.p[dev] = nullptr; g_ws_cache.bytes[dev] = 0;
+            return true;
+        }
+        if (g_ws_cache.p[dev]) {  // too small: give it back before asking for a bigger one
+            (void)hipFree(g_ws_cache.p[dev]);
+            g_ws_cache.p[dev] = nullptr; g_ws_cache.bytes[dev] = 0;
+        }
+    }
+    const hipError_t e = hipMalloc((void**)&p, need);
+    if (e != hipSuccess) { p = nullptr; err = hipGetErrorString(e); return false; }
+    bytes = need;
+    return true;
+}
+void PlaneWorkspace::release() {
+    if (!p) return;
+    void* victim = p;
+    if (device >= 0 && device < 16) {
+        std::lock_guard<std::mutex> lk(g_ws_cache.mu);
+        if (!g_ws_cache.p[device] || g_ws_cache.bytes[device] < bytes) {
+            victim = g_ws_cache.p[device];
+            g_ws_cache.p[device] = p; g_ws_cache.bytes[device] = bytes;
+        }
+    }
+    if (victim) { (void)hipSetDevice(device); (void)hipFree(victim); }
+    p = nullptr; bytes = 0;
+}
+
 struct poa_graph {
     FlatGraph g;
 };
@@ -84,7 +137,8 @@ struct poa_batch {
     DevBuf<uint32_t> d_pred_rows;
     DevBuf<uint8_t> d_qseq;
     DevBuf<uint64_t> d_qoff, d_scratch_off, d_pair_off;
-    DevBuf<uint32_t> d_pitch, d_planes, d_carry, d_score, d_flags, d_npairs;
+    DevBuf<uint32_t> d_pitch, d_carry, d_score, d_flags, d_npairs;
+    PlaneWorkspace d_planes;
     DevBuf<uint2> d_scratch, d_pairs;
     // exact-replay mode (allocated on first use)
     DevBuf<uint32_t> d_succ_off, d_succ_rows, d_dist_min, d_dist_max, d_nbm_off, d_ex_status, d_exit_idx, d_ex_head, d_node_row, d_sp_to_end, d_ex_end;
@@ -286,8 +340,8 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(b->d_pairs.alloc(std::max<uint64_t>(scratch_total, 1)));
     HIP_TRY(b->d_carry.alloc(std::max<uint64_t>(2ull * max_chunk_any * rows, 1)));
     if (n_queries) {
-        hipError_t e = b->d_planes.alloc(ws / 4 + 64);
-        if (e != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, std::string("score-plane workspace: ") + hipGetErrorString(e));
+        std::string werr;
+        if (!b->d_planes.acquire(device, ws + 256, werr)) return fail(POA_ERR_OUT_OF_MEMORY, "score-plane workspace: " + werr);
     }
 
     hipEvent_t e0, e1;
@@ -732,6 +786,7 @@ int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t
 void poa_batch_destroy(poa_batch_t* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    if (b->ran) (void)hipStreamSynchronize(b->last_stream);  // the plane workspace may be handed to another batch next
     delete b;
 }
 
@@ -758,13 +813,41 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
         if (stats) { stats->n_queries = n_queries; stats->n_flagged = n_queries; }
         return POA_OK;
     }
+    // size the workspace for the layout this run will use (2-byte elements when the dense pass can run in u16)
+    uint64_t ws_hint = 0;
+    {
+        uint64_t max_len = 0, elems = 0;
+        for (uint32_t i = 0; i < n_queries; ++i) {
+            const uint64_t L = qoff[i + 1] - qoff[i];
+            max_len = std::max(max_len, L);
+            elems += 3ull * g->g.n * (((L + 1 + 63) / 64) * 64);
+        }
+        const uint64_t ub = (max_len ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * max_len : 0) +
+                            (g->g.min_path_nodes ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * g->g.min_path_nodes : 0);
+        const bool dense = !cfg || (cfg->mode == POA_MODE_DENSE && cfg->span == POA_SPAN_GLOBAL);
+        if (dense && ub <= 65534 && !getenv("POA_PLANES")) {
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && elems * 2 < free_b / 2)
+                ws_hint = elems * 2;
+        }
+    }
     poa_batch_t* b = nullptr;
-    int rc = poa_batch_create(g, device, n_queries, qseq, qoff, 0, &b);
+    int rc = poa_batch_create(g, device, n_queries, qseq, qoff, ws_hint, &b);
     if (rc != POA_OK) return rc;
     rc = poa_batch_run_ex(b, costs, cfg, nullptr);
     if (rc == POA_OK) rc = poa_batch_fetch(b, score, pairs, pair_off, pair_capacity, flags, stats);
     poa_batch_destroy(b);
     return rc;
+}
+
+void poa_release_cache(void) {
+    std::lock_guard<std::mutex> lk(g_ws_cache.mu);
+    for (int d = 0; d < 16; ++d) {
+        if (!g_ws_cache.p[d]) continue;
+        (void)hipSetDevice(d);
+        (void)hipFree(g_ws_cache.p[d]);
+        g_ws_cache.p[d] = nullptr; g_ws_cache.bytes[d] = 0;
+    }
 }
 
 }  // extern "C"
