@@ -132,6 +132,22 @@ def test_multi_strip_long_queries(engine, oracle):
     rb_res, _ = _check_against_dense(engine, oracle, g, qs[4:6], planes=True)
 
 
+def test_one_strip_kernel_shapes(engine, oracle):
+    """The pairs-across-quads kernel (one strip, 512 < widest pitch <= 1024) on a batch of mixed lengths: queries whose
+    second quad is partly or wholly outside their row, short ones whose first quad is too; with both flag encodings
+    (scores below 0x3FFF: two flags ride in the M value; larger gap costs: bit-planes only)."""
+    g, (qseq, qoff) = W.scaled_linearish(880, 40, 20, 6, 1000, p_sub=0.04, p_ins=0.02, p_del=0.02)
+    full = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(6)]
+    qs = [full[0], full[1][:513], full[2][:600], full[3][:777], full[4][:900], full[5][:100], full[0][:1023], full[1][:64], full[2][:960]]
+    for costs in ((4, 6, 2), (9, 40, 12), (3, 1, 1)):
+        res, _ = _check_against_dense(engine, oracle, g, qs, costs=costs)
+        _check_against_astar(oracle, g, qs, res, costs=costs, heuristic=oracle.H_DIJKSTRA, pruning=False)
+    poa = W.LayeredPOA(n_layers=800, width=4, indeg=4, seed=3)     # every row reads several predecessors from the planes
+    qs = poa.queries(5, length=0) + [q[:600] for q in poa.queries(2, length=0, seed=8)]
+    res, _ = _check_against_dense(engine, oracle, poa.graph, qs)
+    _check_against_astar(oracle, poa.graph, qs, res)
+
+
 def test_multi_wave_pipeline(engine, oracle):
     """Long queries run one workgroup per query with the strips pipelined over its waves: mixed lengths in one launch
     (waves beyond a query's last strip exit early), more strips than waves (a second group through the carry array),
