@@ -204,11 +204,12 @@ public:
         uint32_t nc; bool plt, pn;
         // first hop from the end cell: M, then I, then D (gap_affine.rs:832-835)
         Step cur = step(g.end, L, ST_M, nc, plt, pn);
-        if (pn) R.flags |= DF_REF_PANIC;
+        if (pn) { R.flags |= DF_REF_PANIC | DF_TRUNCATED; return; }
         if (cur.found && (nc != 1 || plt)) { R.flags |= DF_AMBIGUOUS; R.n_ambiguous_steps++; }
         if (!cur.found) {
             cur = step(g.end, L, ST_I, nc, plt, pn);
-            if (!cur.found) cur = step(g.end, L, ST_D, nc, plt, pn);
+            if (!cur.found && !pn) cur = step(g.end, L, ST_D, nc, plt, pn);
+            if (pn) { R.flags |= DF_REF_PANIC | DF_TRUNCATED; return; }
             if (!cur.found) {
                 R.flags |= DF_REF_PANIC;
                 if (L <= 3) for (size_t i = 0; i < L; ++i) R.alignment.push_back({g.end, (uint32_t)i});
@@ -220,7 +221,9 @@ public:
         bool reached_start = false;
         for (;;) {
             Step bt = step(cn, cj, cst, nc, plt, pn);
-            if (pn) R.flags |= DF_REF_PANIC;
+            // the reference dies at this step (u32 wrap onto u32::MAX in a Score subtraction): what was emitted so far
+            // stands, nothing after it is defined
+            if (pn) { R.flags |= DF_REF_PANIC; break; }
             if (!bt.found) break;
             if (nc != 1 || plt) { R.flags |= DF_AMBIGUOUS; R.n_ambiguous_steps++; }
             if (cst == ST_M && (bt.st == ST_I || bt.st == ST_D)) { cn = bt.node; cj = bt.j; cst = bt.st; continue; }

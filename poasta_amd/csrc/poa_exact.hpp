@@ -101,15 +101,16 @@ public:
         : G(g), W(w), seq(s), L(len), C(c) {}
 
     // ---- Score arithmetic (scoring/mod.rs:93-152) -------------------------------------------
-    POA_HD uint32_t score_add(uint32_t s, uint64_t rhs) {
+    // (32-bit throughout: the engine refuses graphs / queries whose priorities could reach 2^26, so no sum here can wrap)
+    POA_HD uint32_t score_add(uint32_t s, uint32_t rhs) {
         if (s == EX_INF) { err = EX_PANIC; return 0; }
-        const uint32_t r = s + (uint32_t)rhs;
+        const uint32_t r = s + rhs;
         if (r == EX_INF) { err = EX_PANIC; return 0; }
         return r;
     }
-    POA_HD uint64_t gap_cost(uint32_t st, uint64_t length) const {  // gap_affine.rs:68-80
+    POA_HD uint32_t gap_cost(uint32_t st, uint32_t length) const {  // gap_affine.rs:68-80
         if (length == 0) return 0;
-        return (st == EX_ST_M ? (uint64_t)C.o : 0) + length * (uint64_t)C.e;
+        return (st == EX_ST_M ? C.o : 0u) + length * C.e;
     }
     POA_HD bool is_symbol_equal(uint32_t row, uint8_t c) const {  // graphs/poa.rs:463-465
         return row == G.end_row || G.sym[row] == c;
@@ -206,12 +207,12 @@ public:
     }
 
     // ---- heuristic (heuristic.rs:70-102 / :41-46) --------------------------------------------
-    POA_HD uint64_t h(uint32_t row, uint32_t off, uint32_t st) const {
+    POA_HD uint32_t h(uint32_t row, uint32_t off, uint32_t st) const {
         if (C.heuristic == EX_H_DIJKSTRA) return 0;
-        uint64_t mn = G.dist_min[row]; mn = mn ? mn - 1 : 0;
-        uint64_t mx = G.dist_max[row]; mx = mx ? mx - 1 : 0;
-        const uint64_t tmin = (uint64_t)off + mn, tmax = (uint64_t)off + mx;
-        uint64_t gap;
+        uint32_t mn = G.dist_min[row]; mn = mn ? mn - 1 : 0;
+        uint32_t mx = G.dist_max[row]; mx = mx ? mx - 1 : 0;
+        const uint32_t tmin = off + mn, tmax = off + mx;
+        uint32_t gap;
         if (tmin > L) { gap = tmin - L; if (st != EX_ST_D) st = EX_ST_M; }
         else if (tmax < L) { gap = L - tmax; if (st != EX_ST_I) st = EX_ST_M; }
         else gap = 0;
@@ -220,7 +221,7 @@ public:
 
     // ---- pruning (reached.rs:38-255, gap_affine.rs:780-792) ------------------------------------
     POA_HD bool can_improve_at_offset(uint32_t exit_row, uint32_t to_check, uint32_t score, uint32_t left, uint32_t right,
-                                      uint64_t min_dist_to_end) {
+                                      uint32_t min_dist_to_end) {
         bool have = false;
         uint32_t implicit = 0;
         if (left != EX_NIL && right != EX_NIL) {
@@ -228,13 +229,13 @@ public:
             const uint32_t gl = to_check - left, gr = right - to_check;
             const uint32_t from_left = score_add(ls, gap_cost(EX_ST_M, gl));
             const uint32_t from_right = score_add(rs, gap_cost(EX_ST_M, gr));
-            implicit = ((uint64_t)gr > min_dist_to_end) ? from_left : (from_left < from_right ? from_left : from_right);
+            implicit = (gr > min_dist_to_end) ? from_left : (from_left < from_right ? from_left : from_right);
             have = true;
         } else if (left == EX_NIL && right != EX_NIL) {
             const uint32_t rs = get_score(exit_row, right, EX_ST_M);
             const uint32_t gr = right - to_check;
             const uint32_t from_right = score_add(rs, gap_cost(EX_ST_M, gr));
-            if ((uint64_t)gr > min_dist_to_end) have = false;
+            if (gr > min_dist_to_end) have = false;
             else { implicit = from_right; have = true; }
         } else if (left != EX_NIL) {
             const uint32_t ls = get_score(exit_row, left, EX_ST_M);
@@ -249,8 +250,8 @@ public:
         if (!reached_any(ex)) return true;
         if (row == ex) return true;
         const uint32_t tmin = off + b.min_dist, tmax = off + b.max_dist;
-        uint64_t mde = G.dist_min[ex]; mde = mde ? mde - 1 : 0;
-        if ((uint64_t)tmax > L) return true;
+        uint32_t mde = G.dist_min[ex]; mde = mde ? mde - 1 : 0;
+        if (tmax > L) return true;
         uint32_t prev = reached_before(ex, tmin);
         bool have_last = false;
         uint32_t last_offset = 0;
@@ -297,10 +298,10 @@ public:
 
     // ---- bucket queue (queue.rs:31-70; gap_affine.rs:945-966) ----------------------------------
     POA_HD void queue_state(uint32_t row, uint32_t off, uint32_t st, uint32_t new_score) {
-        const uint64_t pr64 = (uint64_t)new_score + h(row, off, st);
+        const uint32_t pr64 = new_score + h(row, off, st);
         num_queued += 1;
         if (pr64 >= W.n_prio || pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; }
-        const uint32_t prio = (uint32_t)pr64;
+        const uint32_t prio = pr64;
         if (n_layers == 0) { n_layers = 1; layer_min = prio; }
         else if (prio < layer_min) { n_layers += layer_min - prio; layer_min = prio; }
         else if (prio >= layer_min + n_layers) { n_layers = prio - layer_min + 1; }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             }
             const uint32_t ab = __builtin_amdgcn_perm(accB, accA, 0x06020400u);  // [A.q0, B.q0, A.q1, B.q1]
             const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);  // [C.q0, D.q0, C.q1, D.q1]
-            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (MF ? (uint64_t)r * 64u : (uint64_t)r * (pitch / 8)) + lane;
+            uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (MF ? (uint64_t)r * mf_code_stride(pitch) : (uint64_t)r * (pitch / 8)) + lane;
             const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
             if (act_lo) {
                 *reinterpret_cast<uint4*>(Mp + rbase) =

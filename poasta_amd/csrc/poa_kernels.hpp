@@ -182,6 +182,8 @@ __device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j
 
 // code_fmt 2: a stored M value carries two flags — bit 14: I == M, bit 15: D == M — over a 14-bit score (0x3FFF = INF)
 constexpr uint32_t MF_MASK = 0x3FFFu;
+// dwords of [B, D] flag bit-planes per row: one per lane that owns columns of the row (a short row has fewer than 64)
+__host__ __device__ __forceinline__ uint32_t mf_code_stride(uint32_t pitch) { return pitch / 8 < 64u ? pitch / 8 : 64u; }
 __device__ __forceinline__ uint32_t mf_value(uint32_t raw) { const uint32_t v = raw & MF_MASK; return v == MF_MASK ? INF : v; }
 // the score of cell (row, j) of the M plane, whatever the format
 template <typename T>
@@ -193,7 +195,7 @@ __device__ __forceinline__ uint32_t plM(const TbCtx<T>& c, uint32_t row, uint32_
 template <typename T>
 __device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uint32_t j) {
     if (c.code_fmt == 2) {  // one dword per lane and row: bytes [B quad 0, D quad 0, B quad 1, D quad 1], bit k = column 8l + k
-        const uint32_t w = c.codes[(uint64_t)row * 64u + ((j & 511u) >> 3)];
+        const uint32_t w = c.codes[(uint64_t)row * mf_code_stride(c.pitch) + ((j & 511u) >> 3)];
         const uint32_t sh = (j >> 9) * 16u + (j & 7u);
         return (((w >> sh) & 1u) << 1) | (((w >> (sh + 8u)) & 1u) << 3);
     }
@@ -367,23 +369,27 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
             uint32_t nc; bool bad = false, pn = false;
             TbStep cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 0, INF, nc, bad, pn);
             fg = cur.cs;
-            if (pn) f0 |= POA_FLAG_REF_PANIC;
-            if (cur.found && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
-            if (!cur.found) {
+            if (cur.found && !pn && (nc != 1 || bad)) f0 |= POA_FLAG_AMBIGUOUS;
+            if (!cur.found && !pn) {
                 // the end row has no insertion state (I[end] = INF) and keeps its D row in every layout
                 cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 2, INF, nc, bad, pn);  // (full planes: the stored I value is used)
-                if (!cur.found) { cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, pl(c.D, c.pitch, tb_row, tb_off), nc, bad, pn); fg = cur.cs; }
+                if (!cur.found && !pn) { cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, pl(c.D, c.pitch, tb_row, tb_off), nc, bad, pn); fg = cur.cs; }
                 // no backtrace from the end cell: the reference builds a 'simple alignment' for len <= 3 and panics otherwise
                 // (gap_affine.rs:838-853); on a replayed table that is exactly what happened, so only len > 3 is a panic
-                if (!cur.found) { if (!(P.exact_pass && L <= 3)) f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
-                else f0 |= POA_FLAG_AMBIGUOUS;
-                if (cur.found && cur.st == 1) fg = cur.cs - c.e;  // stepped D -> D
+                if (!pn) {
+                    if (!cur.found) { if (!(P.exact_pass && L <= 3)) f0 |= POA_FLAG_REF_PANIC; fallback = 1; }
+                    else f0 |= POA_FLAG_AMBIGUOUS;
+                    if (cur.found && cur.st == 1) fg = cur.cs - c.e;  // stepped D -> D
+                }
             }
+            // a Score subtraction wrapped onto u32::MAX: the reference dies here, nothing is emitted
+            if (pn) { f0 |= POA_FLAG_REF_PANIC; fallback = 2; }
             fr = cur.row; fj = cur.j; fs = cur.st;
         }
         flags |= bc(f0, 0);
         if (bc(fallback, 0)) {
-            if (L <= 3) {
+            if (bc(fallback, 0) == 2) flags |= POA_FLAG_TRUNCATED;
+            if (bc(fallback, 0) == 1 && L <= 3) {
                 if (lane == 0) for (uint32_t i = 0; i < L; ++i) emit_at(i, end_node, L - 1 - i);
                 cnt = L;
             }
@@ -423,11 +429,22 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         const bool regular = active && bt.found && bt.row + 1 == my_row && bt.row != c.start_row &&
                              ((cst == 0 && bt.st == 0 && bt.j + 1 == my_j) || (cst == 1 && bt.st == 1 && bt.j == my_j));
         const uint64_t rb = gballot(regular);
-        const uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
+        uint32_t p = (rb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~rb);  // accepted prefix, <= depth
+        // a Score subtraction that wraps onto u32::MAX kills the reference at that step: the steps before it stand,
+        // nothing after it is defined
+        const uint64_t pnb = gballot(active && pn);
+        const uint32_t first_pn = pnb ? (uint32_t)__builtin_ctzll(pnb) : 64u;
+        const bool dies = first_pn <= p;
+        if (dies) p = first_pn;
         const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
         if (gballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
-        if (gballot(active && pn) & low) flags |= POA_FLAG_REF_PANIC;
         if (gballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
+        if (dies) {
+            if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, cst == 0 ? my_j - 1 : POA_NONE);
+            cnt += p;
+            flags |= POA_FLAG_REF_PANIC;
+            break;
+        }
         if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, cst == 0 ? my_j - 1 : POA_NONE);
         cnt += p;
         if (p == depth) {
@@ -439,10 +456,9 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         }
         // lane p deviates: replay the sequential rule with its results
         const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
-        const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_pn = bc(pn ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
+        const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
         const uint32_t d_cs = bc(bt.cs, p);
         const uint32_t cur_row = crow - p, cur_j = (cst == 0) ? cj - p : cj, cur_st = cst;  // speculation keeps the state
-        if (d_pn) flags |= POA_FLAG_REF_PANIC;
         if (!d_found) break;
         if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
         if (cur_st == 0 && d_st != 0) {  // zero-cost gap close: no pair (gap_affine.rs:871-875)

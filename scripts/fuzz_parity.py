@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised differential run (GPU box): the HIP path against the oracle on random graphs, costs and query lengths —
+dense mode vs the oracle's dense restatement (scores, alignments, flags), exact mode vs the oracle's A*.
+Test infrastructure; prints one JSON line; non-zero exit on the first difference."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as O
+from poasta_amd import aligner as E, workloads as W
+from poasta_amd.graph import pack_queries
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=200)
+ap.add_argument("--first", type=int, default=0)
+ap.add_argument("--seconds", type=float, default=240.0)
+args = ap.parse_args()
+t0 = time.time()
+n_dense = n_exact = n_cases = 0
+for seed in range(args.first, args.first + args.seeds):
+    if time.time() - t0 > args.seconds:
+        break
+    rng = np.random.Generator(np.random.PCG64(77000 + seed))
+    kind = seed % 4
+    if kind == 0:
+        alpha = b"AC" if seed % 8 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 40)), p_edge=float(rng.uniform(0.1, 0.4)), alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, float(rng.uniform(0.05, 0.5)), alpha) for _ in range(12)]
+    elif kind == 1:
+        nb = int(rng.integers(200, 1100))
+        L = int(rng.integers(max(64, nb - 300), nb + 150))
+        g, (qseq, qoff) = W.scaled_linearish(nb, int(nb * 0.05), int(nb * 0.025), 6, L, graph_seed=seed, query_seed=seed + 1,
+                                             p_sub=float(rng.uniform(0.01, 0.1)), p_ins=0.02, p_del=0.02)
+        qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(6)]
+        qs += [qs[0][:int(rng.integers(1, len(qs[0])))], qs[1][:int(rng.integers(1, len(qs[1])))]]
+    elif kind == 2:
+        poa = W.LayeredPOA(n_layers=int(rng.integers(20, 400)), width=int(rng.integers(2, 5)), indeg=int(rng.integers(1, 4)), seed=seed)
+        g = poa.graph
+        qs = poa.queries(6, length=0, seed=seed + 3)
+    else:
+        pg = W.PangenomePOA(ref_len=int(rng.integers(100, 900)), n_hap=int(rng.integers(2, 8)), p_snp=0.02, p_indel=0.01, max_indel=6, seed=seed)
+        g = pg.graph
+        qs = pg.queries(6, length=int(rng.integers(50, 700)), seed=seed + 5)
+    costs = (int(rng.integers(1, 10)), int(rng.integers(0, 13)), int(rng.integers(1, 5)))
+    qseq, qoff = pack_queries(qs)
+    og = O.OracleGraph.from_csr(g.as_dict())
+    oc = O.Costs(*costs)
+    m, o, e = costs
+    al = E.PoastaAligner(E.AffineMinGapCost(E.GapAffine(m, e, o)))
+    res = al.align_batch(g, qseq=qseq, qoff=qoff)
+    D = og.dense_batch(qseq, qoff, oc, threads=8)
+    for i in range(len(qs)):
+        ok = int(res.score[i]) == int(D["score"][i]) and res.raw_alignment(i) == O.batch_alignment(D, i) and int(res.flags[i]) == int(D["flags"][i])
+        if not ok:
+            print(json.dumps(dict(fail="dense", seed=seed, kind=kind, query=i, costs=costs, gpu=[int(res.score[i]), int(res.flags[i])],
+                                  oracle=[int(D["score"][i]), int(D["flags"][i])])))
+            sys.exit(1)
+        n_dense += 1
+    if g.n * max(len(q) for q in qs) < 400000:
+        heur, prune = (O.H_MINGAP, True) if seed % 3 else (O.H_DIJKSTRA, seed % 2 == 0)
+        cfgc = E.AffineMinGapCost if heur == O.H_MINGAP else E.AffineDijkstra
+        ax = E.PoastaAligner(cfgc(E.GapAffine(m, e, o)), mode="exact", queue_entries_per_cell=12.0)
+        rx = ax.align_batch(g, qseq=qseq, qoff=qoff, pruning=prune)
+        A = og.astar_batch(qseq, qoff, oc, heur, prune, threads=8)
+        for i in range(len(qs)):
+            if A["status"][i] != 0:
+                ok = bool(int(rx.flags[i]) & 4)
+            else:
+                ok = int(rx.flags[i]) & ~0x10 == 0 and int(rx.score[i]) == int(A["score"][i]) and rx.raw_alignment(i) == O.batch_alignment(A, i)
+            if not ok:
+                print(json.dumps(dict(fail="exact", seed=seed, kind=kind, query=i, costs=costs, heur=heur, prune=prune,
+                                      gpu=[int(rx.score[i]), int(rx.flags[i])], oracle=[int(A["status"][i]), int(A["score"][i])])))
+                sys.exit(1)
+            n_exact += 1
+    n_cases += 1
+print(json.dumps(dict(ok=True, graphs=n_cases, dense_queries=n_dense, exact_queries=n_exact, seconds=round(time.time() - t0, 1))))

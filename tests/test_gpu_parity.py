@@ -268,3 +268,16 @@ def test_error_codes(engine):
     with pytest.raises(_lib.PoaError) as ei:
         engine.DeviceGraph(FlatGraph(4, 0, 1, sym, succ_off, succ, pred_off, pred))
     assert ei.value.code == -2
+
+
+def test_randomised_differential_run(engine):
+    """scripts/fuzz_parity.py: random graphs / costs / lengths, dense mode vs the oracle's dense restatement and exact mode
+    vs its A*.  Seeds 81 and 409 are the two differences the first long run found (flag plane of a < 64-column row inside
+    a one-strip batch; what is emitted after a step at which the reference panics), then a fresh block of seeds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for args in (["--first", "81", "--seeds", "1"], ["--first", "409", "--seeds", "1"], ["--first", "2000", "--seeds", "48", "--seconds", "60"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py")] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
