@@ -96,6 +96,9 @@ struct VisitedStorage {
     }
     inline Score* cell(const AlnNode& a, AlignState st, bool create) {
         uint32_t rank = node_ranks[a.node];
+        // (the reference's per-block hash maps take any offset; this flat index does not: an ends-free search that is never
+        // allowed to end keeps opening insertions past the query — there the reference itself only stops on u32 overflow)
+        if (a.offset / B >= n_oblocks) throw RefPanic("offset beyond the visited table: the search cannot end");
         size_t ti = (size_t)(rank / B) * n_oblocks + a.offset / B;
         int32_t t = tile_ix[ti];
         if (t < 0) {

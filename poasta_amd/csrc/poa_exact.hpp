@@ -121,8 +121,13 @@ public:
         uint32_t* p = st == EX_ST_M ? W.M : (st == EX_ST_I ? W.I : W.D);
         return p + (uint64_t)row * W.pitch + off;
     }
-    POA_HD uint32_t get_score(uint32_t row, uint32_t off, uint32_t st) const { return *cell(row, off, st); }
+    // Offsets beyond the row: the reference's table is a hash of tiles and takes any offset — an ends-free search that is
+    // not allowed to stop at the query end opens an insertion at offset len + 1 (expand_ref_graph_end has no bound,
+    // gap_affine.rs:346-368).  The flat planes have `pitch` columns: beyond them a cell reads as unvisited and a write
+    // is a workspace overflow (the query keeps its flag, nothing is written out of bounds).
+    POA_HD uint32_t get_score(uint32_t row, uint32_t off, uint32_t st) const { return off < W.pitch ? *cell(row, off, st) : EX_INF; }
     POA_HD bool update_if_lower(uint32_t row, uint32_t off, uint32_t st, uint32_t s) {
+        if (off >= W.pitch) { err = EX_POOL_FULL; return false; }
         uint32_t* p = cell(row, off, st);
         if (s < *p) { *p = s; return true; }
         return false;
@@ -134,6 +139,7 @@ public:
         const uint32_t x = G.exit_idx[row];
         if (x == EX_NIL) return;
         const uint32_t wi = off >> 6;
+        if (wi >= W.wpn) { err = EX_POOL_FULL; return; }
         uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
         const uint64_t old = *w;
         *w = old | (1ull << (off & 63));
