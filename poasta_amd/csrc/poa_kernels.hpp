@@ -165,6 +165,7 @@ struct TbStep {
     uint32_t row, j, st;  // st: 0 M, 1 D, 2 I
     bool found;
     uint32_t cs;          // score of the cell the step started from
+    uint32_t node;        // node of the row the step started from (for the emitted pair: no second, dependent load)
 };
 
 template <typename T>
@@ -213,9 +214,10 @@ __device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uin
 template <typename T, bool COMPACT>
 __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st, uint32_t gap_cs, uint32_t& n_cand,
                                  bool& bad, bool& panic) {
-    TbStep first{0, 0, 0, false, 0};
+    TbStep first{0, 0, 0, false, 0, 0};
     n_cand = 0;
     const RowMeta m = c.rows[row];
+    first.node = m.node;
     const bool is_end = (m.flags & ROW_END) != 0;
     auto sub = [&](uint32_t a, uint32_t b) { uint32_t r = a - b; if (r == INF) panic = true; return r; };
     auto cand = [&](uint32_t r2, uint32_t j2, uint32_t s2) {
@@ -418,7 +420,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         const bool active = lane < depth;
         const uint32_t my_row = crow - lane, my_j = (cst == 0) ? cj - lane : cj;
         const uint32_t my_gcs = (cst == 1) ? gcs - lane * c.e : gcs;
-        TbStep bt{0, 0, 0, false, 0};
+        TbStep bt{0, 0, 0, false, 0, 0};
         uint32_t nc = 0;
         bool bad = false, pn = false;
         if (active) bt = tb_step<T, COMPACT>(c, my_row, my_j, cst, my_gcs, nc, bad, pn);
@@ -440,12 +442,12 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         if (gballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;
         if (gballot(quirk) & low) flags |= POA_FLAG_START_QUIRK;
         if (dies) {
-            if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, cst == 0 ? my_j - 1 : POA_NONE);
+            if (lane < p) emit_at(cnt + lane, bt.node, cst == 0 ? my_j - 1 : POA_NONE);
             cnt += p;
             flags |= POA_FLAG_REF_PANIC;
             break;
         }
-        if (lane < p) emit_at(cnt + lane, c.rows[my_row].node, cst == 0 ? my_j - 1 : POA_NONE);
+        if (lane < p) emit_at(cnt + lane, bt.node, cst == 0 ? my_j - 1 : POA_NONE);
         cnt += p;
         if (p == depth) {
             // every speculated step was regular: continue below the last one, in the same state
@@ -457,8 +459,8 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         // lane p deviates: replay the sequential rule with its results
         const uint32_t d_found = bc(bt.found ? 1u : 0u, p), d_row = bc(bt.row, p), d_j = bc(bt.j, p), d_st = bc(bt.st, p);
         const uint32_t d_amb = bc(amb ? 1u : 0u, p), d_quirk = bc(quirk ? 1u : 0u, p);
-        const uint32_t d_cs = bc(bt.cs, p);
-        const uint32_t cur_row = crow - p, cur_j = (cst == 0) ? cj - p : cj, cur_st = cst;  // speculation keeps the state
+        const uint32_t d_cs = bc(bt.cs, p), d_node = bc(bt.node, p);
+        const uint32_t cur_j = (cst == 0) ? cj - p : cj, cur_st = cst;  // the cell is (crow - p, cur_j); speculation keeps the state
         if (!d_found) break;
         if (d_amb) flags |= POA_FLAG_AMBIGUOUS;
         if (cur_st == 0 && d_st != 0) {  // zero-cost gap close: no pair (gap_affine.rs:871-875)
@@ -467,7 +469,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
             continue;
         }
         if (lane == 0) {
-            const uint32_t node = c.rows[cur_row].node;
+            const uint32_t node = d_node;
             if (cur_st == 0) emit_at(cnt, node, cur_j - 1);
             else if (cur_st == 2) emit_at(cnt, POA_NONE, cur_j - 1);
             else emit_at(cnt, node, POA_NONE);
