@@ -16,6 +16,8 @@
 
 namespace poa_amd {
 
+typedef __attribute__((address_space(4))) const uint32_t CPredRows;  // read-only graph table: scalar loads
+
 typedef unsigned short poa_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ poa_u16x2 pkv(uint32_t a) { return __builtin_bit_cast(poa_u16x2, a); }
 __device__ __forceinline__ uint32_t pku(poa_u16x2 a) { return __builtin_bit_cast(uint32_t, a); }
@@ -297,35 +299,61 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                 // on the same graph row of BOTH waves, so that the producer has released before it published the row.
                 if (MW && (meta.flags & ROW_FAR_PRED)) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 else if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
-                    const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
-                    const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
-                    uint32_t tm[NP], td[NP];
-                    if (pr + 1 == r) {
+                // Predecessors in batches of PB: all row indices first (scalar loads), then every plane load of the batch,
+                // then the reduction — one memory round-trip per batch instead of two per predecessor (a bubble-rich graph
+                // reads 2-4 predecessor rows on every row).
+                constexpr int PB = Q == 1 ? 4 : 2;
+                const CPredRows* cpred = (const CPredRows*)P.pred_rows + meta.pred_begin;
+                for (uint32_t pe0 = 0; pe0 < meta.pred_count; pe0 += PB) {
+                    uint32_t prs[PB];
+                    bool valid[PB], in_regs[PB];
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) { tm[p] = Mprev[p]; td[p] = Dprev[p]; }
-                    } else {
+                    for (int b = 0; b < PB; ++b) {
+                        valid[b] = pe0 + b < meta.pred_count;
+                        prs[b] = valid[b] ? cpred[pe0 + b] : 0u;
+                        in_regs[b] = prs[b] + 1 == r;  // the previous row is still in registers
+                    }
+                    uint4 la[PB][Q], lb[PB][Q];
+                    uint32_t edges[PB];
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        const uint64_t pbase = (uint64_t)prs[b] * pitch + sbase + K * lane;
 #pragma unroll
                         for (int m = 0; m < Q; ++m) {
-                            uint4 a = make_uint4(inf2, inf2, inf2, inf2), b = a;
-                            if (act[m]) {
-                                a = *reinterpret_cast<const uint4*>(Mp + pbase + m * QW);
-                                b = *reinterpret_cast<const uint4*>(Dp + pbase + m * QW);
+                            la[b][m] = make_uint4(inf2, inf2, inf2, inf2); lb[b][m] = la[b][m];
+                            if (valid[b] && !in_regs[b] && act[m]) {
+                                la[b][m] = *reinterpret_cast<const uint4*>(Mp + pbase + m * QW);
+                                lb[b][m] = *reinterpret_cast<const uint4*>(Dp + pbase + m * QW);
                             }
-                            tm[4 * m] = a.x; tm[4 * m + 1] = a.y; tm[4 * m + 2] = a.z; tm[4 * m + 3] = a.w;
-                            td[4 * m] = b.x; td[4 * m + 1] = b.y; td[4 * m + 2] = b.z; td[4 * m + 3] = b.w;
+                        }
+                        edges[b] = inf2;
+                        if (valid[b]) {
+                            if (from_ring && r - prs[b] <= ROW_NEAR) edges[b] = mw_ring[wave - 1][(prog_base + prs[b]) % MW_RING][2] << 16;
+                            else if (s > 0) edges[b] = (uint32_t)Mp[(uint64_t)prs[b] * pitch + sbase - 1] << 16;
                         }
                     }
-                    uint32_t edge = inf2;
-                    if (from_ring && r - pr <= ROW_NEAR) edge = mw_ring[wave - 1][(prog_base + pr) % MW_RING][2] << 16;
-                    else if (s > 0) edge = (uint32_t)Mp[(uint64_t)pr * pitch + sbase - 1] << 16;
 #pragma unroll
-                    for (int m = 0; m < Q; ++m) {
-                        PMl[m] = pk_min(PMl[m], pk_wave_shr1(tm[4 * m + 3], edge));
-                        edge = (uint32_t)__builtin_amdgcn_readlane((int)tm[4 * m + 3], 63);
+                    for (int b = 0; b < PB; ++b) {
+                        if (!valid[b]) continue;
+                        uint32_t tm[NP], td[NP];
+#pragma unroll
+                        for (int m = 0; m < Q; ++m) {
+                            tm[4 * m] = la[b][m].x; tm[4 * m + 1] = la[b][m].y; tm[4 * m + 2] = la[b][m].z; tm[4 * m + 3] = la[b][m].w;
+                            td[4 * m] = lb[b][m].x; td[4 * m + 1] = lb[b][m].y; td[4 * m + 2] = lb[b][m].z; td[4 * m + 3] = lb[b][m].w;
+                        }
+                        if (in_regs[b]) {
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) { tm[p] = Mprev[p]; td[p] = Dprev[p]; }
+                        }
+                        uint32_t edge = edges[b];
+#pragma unroll
+                        for (int m = 0; m < Q; ++m) {
+                            PMl[m] = pk_min(PMl[m], pk_wave_shr1(tm[4 * m + 3], edge));
+                            edge = (uint32_t)__builtin_amdgcn_readlane((int)tm[4 * m + 3], 63);
+                        }
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) { PM[p] = pk_min(PM[p], tm[p]); PD[p] = pk_min(PD[p], td[p]); }
                     }
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) { PM[p] = pk_min(PM[p], tm[p]); PD[p] = pk_min(PD[p], td[p]); }
                 }
                 row_body(PM, PD);
             }
