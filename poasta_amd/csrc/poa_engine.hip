@@ -203,6 +203,13 @@ static void collect_stats(poa_batch* b, poa_stats_t* stats) {
     b->runs.clear();
 }
 
+// the 1024-column multi-wave kernel when the chunk fills the chip with one wave per 1024 columns (else 512-column strips of
+// the adjacent-pairs kernel give twice the waves)
+static bool pxmw_ok(uint32_t count, uint32_t max_pitch) {
+    if (const char* v = getenv("POA_PXMW")) return atoi(v) != 0;
+    return (uint64_t)count * ((max_pitch + 1023) / 1024) >= 1024;
+}
+
 extern "C" {
 
 const char* poa_version(void) { return "poasta_amd 0.1 (gfx950)"; }
@@ -546,6 +553,11 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                     tp.code_fmt = mf ? 2u : 1u;
                     if (mf) hipLaunchKernelGGL(poa_forward_px_kernel<true>, dim3(blocks), dim3(256), 0, stream, fp);
                     else hipLaunchKernelGGL(poa_forward_px_kernel<false>, dim3(blocks), dim3(256), 0, stream, fp);
+                } else if (mw && pxmw_ok(ch.count, max_pitch)) {
+                    // pairs-across-quads mapping, 1024-column strips pipelined over the waves of a workgroup
+                    tp.code_fmt = 1;
+                    const uint32_t waves = std::min<uint32_t>((max_pitch + 1023) / 1024, MW_MAX_WAVES);
+                    hipLaunchKernelGGL(poa_forward_pxmw_kernel, dim3(ch.count), dim3(64 * waves), 0, stream, fp);
                 } else if (mw) {
                     // narrow strips (more waves) until the chunk alone fills the chip
                     if (!quads_override) quads = ((uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192) ? 2 : 1;

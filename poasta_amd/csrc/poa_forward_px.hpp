@@ -293,4 +293,253 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     if (r < P.n_rows) do_row(r, MA, DA, MB, DB);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same register mapping for queries longer than one strip: one WORKGROUP per query, wave w computes the 1024-column
+// strip g*S + w, the strips running as the software pipeline described at poa_forward_packed_kernel (LDS hand-over ring
+// with back-pressure, LDS-only fences, ROW_NEAR look-back for multi-predecessor rows, far predecessors and later groups
+// through the planes / the carry array).  What differs from the one-strip kernel: values enter quad 0 from the previous
+// strip (scan carry, I and M of its last column), and leave quad 1 towards the next one.  Flags: bit-planes (code_fmt 1);
+// symbol masks are computed (the LDS holds the ring; 16 waves of tables would not fit).
+__global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
+    constexpr int K = 8;
+    constexpr uint32_t QW = 64 * K, W = 2 * QW;
+    constexpr uint32_t I16 = 0xFFFFu, INF2 = 0xFFFFFFFFu;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t S = blockDim.x >> 6;
+    __shared__ uint32_t mw_progress[MW_MAX_WAVES];
+    __shared__ uint32_t mw_ring[MW_MAX_WAVES][MW_RING][4];  // {scan carry, I last col, M last col, -}
+    if (threadIdx.x < MW_MAX_WAVES) mw_progress[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t wq = blockIdx.x;
+    if (wq >= P.n_queries) return;
+    const uint32_t qi = P.first_query + wq;
+    const uint64_t qbeg = P.qoff[qi];
+    const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
+    const uint8_t* __restrict__ q = P.qseq + qbeg;
+    const uint32_t pitch = P.pitch[qi];
+    const uint64_t RP = (uint64_t)P.n_rows * pitch;
+    uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
+    uint16_t* __restrict__ Ip = Mp + RP;
+    uint16_t* __restrict__ Dp = Ip + RP;
+    uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;
+    const uint32_t e = P.cost_e, oe = P.cost_oe, x = P.cost_x;
+    const uint32_t e2 = e | (e << 16), oe2 = oe | (oe << 16), x2 = x | (x << 16);
+    auto pack16 = [](uint32_t v) { v = v < I16 ? v : I16; return v | (v << 16); };
+    auto clamp16 = [](uint32_t v) { return v < I16 ? v : I16; };
+    const uint32_t step = K * e;
+    const uint32_t step2 = pack16(step);
+    const uint32_t w15_2 = pack16(((lane & 15u) + 1u) * step);
+    const uint32_t w31_2 = pack16(lane >= 32u ? (lane - 31u) * step : 0u);
+    const uint32_t lane_off2 = pack16(K * lane * e);
+    const uint32_t n_strips = (pitch + W - 1) / W;
+    const uint32_t n_groups = (n_strips + S - 1) / S;
+    const CRowWords* crows = (const CRowWords*)P.rows;
+    const CU32* cpred = (const CU32*)P.pred_rows;
+
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t s = g * S + wave;
+        if (s >= n_strips) break;
+        const bool from_ring = wave > 0;
+        const bool from_global = s > 0 && !from_ring;
+        const bool to_ring = wave + 1 < S && s + 1 < n_strips;
+        const bool to_global = s + 1 < n_strips && !to_ring;
+        const uint32_t prog_base = g * P.n_rows;
+        uint32_t m_edge_prev = I16;  // from_ring: M[r-1][sbase-1]
+        if (from_global) {
+            mw_wait_gt(&mw_progress[S - 1], prog_base - 1);  // the whole previous group is done and released
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const uint32_t sbase = s * W;
+        const uint32_t c_lo = sbase + K * lane, c_hi = sbase + QW + K * lane;
+        const bool act_lo = c_lo < pitch, act_hi = c_hi < pitch;
+        uint32_t qP[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t a = (c_lo + k < L) ? (uint32_t)q[c_lo + k] : 0u, b = (c_hi + k < L) ? (uint32_t)q[c_hi + k] : 0u;
+            qP[k] = a | (b << 16);
+        }
+        const uint32_t qlE = ((c_lo > 0 && c_lo - 1 < L) ? (uint32_t)q[c_lo - 1] : 0u) | (((c_hi - 1 < L) ? (uint32_t)q[c_hi - 1] : 0u) << 16);
+
+        auto do_row = [&](const uint32_t r, const uint32_t (&Mprev)[K], const uint32_t (&Dprev)[K], uint32_t (&Mout)[K], uint32_t (&Dout)[K]) {
+            const poa_u32x4 mw = crows[r];
+            struct { uint32_t pred_begin, pred_count, sym, child_sym, flags; } meta{mw.y, mw.z, mw.w & 0xFFu, (mw.w >> 8) & 0xFFu, (mw.w >> 16) & 0xFFu};
+            const uint32_t sym2 = meta.sym | (meta.sym << 16);
+            const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
+            uint32_t in_cq = I16, in_ilast = I16, in_mlast = I16;
+            if (from_ring) {
+                mw_wait_gt(&mw_progress[wave - 1], prog_base + r);
+                const uint32_t* slot = mw_ring[wave - 1][(prog_base + r) % MW_RING];
+                in_cq = slot[0]; in_ilast = slot[1]; in_mlast = slot[2];
+            }
+            // lane l <- v of lane l-1; lane 0: lo half <- `left` (last column of the previous strip), hi half <- lane 63's lo half
+            auto shr_lane = [&](uint32_t v, uint32_t left) {
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+                return pk_wave_shr1(v, (left & 0xFFFFu) | (last << 16));
+            };
+            uint32_t PMl = INF2;
+            uint32_t cq_out = I16, i_out = I16, m_out = I16;
+
+            auto row_body = [&](const uint32_t (&PM)[K], const uint32_t (&PD)[K]) {
+                uint32_t (&Mc)[K] = Mout;
+                uint32_t (&Dc)[K] = Dout;
+                uint32_t Ic[K], PDe[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], e2);
+                if (meta.flags & ROW_END) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        Dc[k] = PDe[k];
+                        Mc[k] = pk_min(PM[k], Dc[k]);
+                        Ic[k] = INF2;
+                    }
+                } else {
+                    const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
+                    const uint32_t csym2 = cs1 | (cs1 << 16);
+                    const uint32_t start_keep = ((meta.flags & ROW_START) && sbase == 0 && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                    uint32_t Hc[K];
+                    uint32_t pm_left = PMl;
+                    uint32_t cost_left = pk_sub_sat(x2, pk_shl<8>(pk_is_zero(qlE ^ sym2)));
+                    uint32_t t = INF2;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const uint32_t eq1 = pk_is_zero(qP[k] ^ sym2);
+                        Dc[k] = pk_min(PDe[k], pk_inf_where(pk_add_sat(PM[k], oe2), eq1));
+                        Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
+                        if (k == 0) Hc[k] &= start_keep;
+                        pm_left = PM[k];
+                        cost_left = pk_sub_sat(x2, pk_shl<8>(eq1));
+                        const uint32_t a = pk_inf_where(pk_add_sat(Hc[k], oe2), pk_is_zero(qP[k] ^ csym2));
+                        Ic[k] = t;
+                        t = pk_min(pk_add_sat(t, e2), a);
+                    }
+                    const uint32_t Pm = wave_scan_min_plus_pk(t, step2, w15_2, w31_2);
+                    const uint32_t excl = pk_wave_shr1(Pm, INF2);
+                    const uint32_t totals = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
+                    // scan carries: into quad 0 from the previous strip, into quad 1 from quad 0, out of quad 1 to the next strip
+                    const uint32_t cq_lo = from_ring ? in_cq : (from_global ? carry[2 * r] : I16);
+                    const uint32_t cq_hi = umin(clamp16(cq_lo + QW * e), totals & 0xFFFFu);
+                    cq_out = umin(clamp16(cq_hi + QW * e), totals >> 16);
+                    const uint32_t cin = pk_min(excl, pk_add_sat((cq_lo & 0xFFFFu) | (cq_hi << 16), lane_off2));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        Ic[k] = pk_min(Ic[k], pk_add_sat(cin, (uint32_t)k * e2));
+                        Mc[k] = pk_min(Hc[k], Ic[k]);
+                    }
+                    if (to_global && lane == 0) carry[2 * r] = cq_out;
+                }
+
+                // flag bit-planes
+                const uint32_t edge_i = from_ring ? in_ilast : (from_global ? carry[2 * r + 1] : I16);
+                uint32_t i_left = shr_lane(Ic[K - 1], edge_i);
+                uint32_t accA = 0, accB = 0, accC = 0, accD = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    accA |= pk_eq_ge(Ic[k], Mc[k]) << k;
+                    accB |= pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]) << k;
+                    accC |= pk_eq_ge(Dc[k], Mc[k]) << k;
+                    accD |= pk_eq_ge(PDe[k], Dc[k]) << k;
+                    i_left = Ic[k];
+                }
+                const uint32_t ab = __builtin_amdgcn_perm(accB, accA, 0x06020400u);
+                const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);
+                uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
+                const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+                if (act_lo) {
+                    *reinterpret_cast<uint4*>(Mp + rbase) =
+                        make_uint4(pk_lo_lo(Mc[0], Mc[1]), pk_lo_lo(Mc[2], Mc[3]), pk_lo_lo(Mc[4], Mc[5]), pk_lo_lo(Mc[6], Mc[7]));
+                    codes[0] = pk_lo_lo(ab, cd);
+                    if (keep_d)
+                        *reinterpret_cast<uint4*>(Dp + rbase) =
+                            make_uint4(pk_lo_lo(Dc[0], Dc[1]), pk_lo_lo(Dc[2], Dc[3]), pk_lo_lo(Dc[4], Dc[5]), pk_lo_lo(Dc[6], Dc[7]));
+                }
+                if (act_hi) {
+                    *reinterpret_cast<uint4*>(Mp + rbase + QW) =
+                        make_uint4(pk_hi_hi(Mc[0], Mc[1]), pk_hi_hi(Mc[2], Mc[3]), pk_hi_hi(Mc[4], Mc[5]), pk_hi_hi(Mc[6], Mc[7]));
+                    codes[QW / 8] = pk_hi_hi(ab, cd);
+                    if (keep_d)
+                        *reinterpret_cast<uint4*>(Dp + rbase + QW) =
+                            make_uint4(pk_hi_hi(Dc[0], Dc[1]), pk_hi_hi(Dc[2], Dc[3]), pk_hi_hi(Dc[4], Dc[5]), pk_hi_hi(Dc[6], Dc[7]));
+                }
+                // what the next strip needs of this row: I and M of my last column (quad 1, lane 63, register 7)
+                i_out = (uint32_t)__builtin_amdgcn_readlane((int)Ic[K - 1], 63) >> 16;
+                m_out = (uint32_t)__builtin_amdgcn_readlane((int)Mc[K - 1], 63) >> 16;
+                if (to_global && lane == 63) carry[2 * r + 1] = Ic[K - 1] >> 16;
+            };
+
+            if (meta.flags & ROW_CHAIN) {
+                uint32_t edge = I16;
+                if (from_ring) edge = m_edge_prev;
+                else if (from_global) edge = (uint32_t)Mp[(uint64_t)(r - 1) * pitch + sbase - 1];
+                PMl = shr_lane(Mprev[K - 1], edge);
+                row_body(Mprev, Dprev);
+            } else {
+                uint32_t PM[K], PD[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) { PM[k] = INF2; PD[k] = INF2; }
+                if (meta.flags & ROW_FAR_PRED) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                else if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
+                    const uint32_t pr = cpred[meta.pred_begin + pe];
+                    uint32_t tm[K], td[K];
+                    if (pr + 1 == r) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
+                    } else {
+                        const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
+                        uint4 m0 = make_uint4(INF2, INF2, INF2, INF2), d0 = m0, m1 = m0, d1 = m0;
+                        if (act_lo) {
+                            m0 = *reinterpret_cast<const uint4*>(Mp + pbase);
+                            d0 = *reinterpret_cast<const uint4*>(Dp + pbase);
+                        }
+                        if (act_hi) {
+                            m1 = *reinterpret_cast<const uint4*>(Mp + pbase + QW);
+                            d1 = *reinterpret_cast<const uint4*>(Dp + pbase + QW);
+                        }
+                        const uint32_t a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
+                        const uint32_t b0[4] = {d0.x, d0.y, d0.z, d0.w}, b1[4] = {d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            tm[2 * i] = pk_lo_lo(a0[i], a1[i]); tm[2 * i + 1] = pk_hi_hi(a0[i], a1[i]);
+                            td[2 * i] = pk_lo_lo(b0[i], b1[i]); td[2 * i + 1] = pk_hi_hi(b0[i], b1[i]);
+                        }
+                    }
+                    uint32_t edge = I16;
+                    if (from_ring && r - pr <= ROW_NEAR) edge = mw_ring[wave - 1][(prog_base + pr) % MW_RING][2];
+                    else if (s > 0) edge = (uint32_t)Mp[(uint64_t)pr * pitch + sbase - 1];
+                    PMl = pk_min(PMl, shr_lane(tm[K - 1], edge));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { PM[k] = pk_min(PM[k], tm[k]); PD[k] = pk_min(PD[k], td[k]); }
+                }
+                row_body(PM, PD);
+            }
+
+            if (to_ring) {
+                // back-pressure: the consumer may still look ROW_NEAR rows back from the row it is working on
+                if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING);
+                if (lane == 63) {
+                    uint32_t* slot = mw_ring[wave][(prog_base + r) % MW_RING];
+                    slot[0] = cq_out; slot[1] = i_out; slot[2] = m_out;
+                }
+            }
+            if (to_global && r + 1 == P.n_rows) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_store(&mw_progress[wave], prog_base + r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            m_edge_prev = in_mlast;
+        };
+
+        uint32_t MA[K], DA[K], MB[K], DB[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { MA[k] = INF2; DA[k] = INF2; }
+        uint32_t r = 0;
+        for (; r + 1 < P.n_rows; r += 2) {
+            do_row(r, MA, DA, MB, DB);
+            do_row(r + 1, MB, DB, MA, DA);
+        }
+        if (r < P.n_rows) do_row(r, MA, DA, MB, DB);
+        if (n_strips > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
 }  // namespace poa_amd

@@ -26,6 +26,9 @@ if args.config == "2":
     g, (qseq, qoff) = W.config2(n_queries=args.queries or 10000)
 elif args.config == "5":
     g, (qseq, qoff) = W.config5(n_queries=args.queries or 2000)
+elif args.config == "long":
+    # long reads on a linear-ish graph: 10 kbp x 10 752 rows (config 2's family, ten times longer)
+    g, (qseq, qoff) = W.scaled_linearish(10000, 500, 250, args.queries or 1500, 10000)
 elif args.config == "4":
     g, (qseq, qoff) = W.config4(n_queries=args.queries or 5000)
 else:
