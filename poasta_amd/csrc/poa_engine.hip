@@ -770,6 +770,7 @@ int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t
     if (!b || !m || !i || !d) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: null argument");
     if (!b->ran || query >= b->n_queries) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: bad query / not run");
     if (b->compact) return fail(POA_ERR_UNSUPPORTED, "poa_batch_fetch_planes: the last run used the compact layout; run with POA_CFG_FULL_PLANES");
+    if (b->last_mode != POA_MODE_DENSE) return fail(POA_ERR_UNSUPPORTED, "poa_batch_fetch_planes: after an exact / hybrid run the workspace holds the replayed search's tiled table");
     const auto& last = b->cur().chunks.back();
     if (query < last.first || query >= last.first + last.count)
         return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_planes: the query's planes were overwritten by a later chunk");

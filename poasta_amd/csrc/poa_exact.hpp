@@ -57,8 +57,8 @@ struct ExQEntry { uint32_t score, row, offset, next; };
 struct ExStackEntry { uint32_t row, offset, it; };
 
 struct ExactWork {  // per query
-    uint32_t* M; uint32_t* I; uint32_t* D;  // visited planes [row * pitch + offset], INF-initialised
-    uint32_t pitch;
+    uint32_t* T;            // visited table, tiled (ex_cell_index), INF-initialised; states: EX_ST_M / EX_ST_D / EX_ST_I
+    uint32_t n_rows, pitch;
     uint64_t* reached;      // [n_exit * wpn] bitset of offsets reached in Match state, one row per bubble exit
     uint64_t* rsum;         // [n_exit * swpn] summary: bit w set iff word w of that exit's bitset is non-zero
     uint32_t wpn, swpn;
@@ -118,8 +118,7 @@ public:
 
     // ---- visited table (gap_affine.rs:483-548) -----------------------------------------------
     POA_HD uint32_t* cell(uint32_t row, uint32_t off, uint32_t st) const {
-        uint32_t* p = st == EX_ST_M ? W.M : (st == EX_ST_I ? W.I : W.D);
-        return p + (uint64_t)row * W.pitch + off;
+        return W.T + ex_cell_index(row, off, st, W.n_rows, W.pitch);
     }
     // Offsets beyond the row: the reference's table is a hash of tiles and takes any offset — an ends-free search that is
     // not allowed to stop at the query end opens an insertion at offset len + 1 (expand_ref_graph_end has no bound,

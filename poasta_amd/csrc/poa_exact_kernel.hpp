@@ -77,11 +77,9 @@ __global__ __launch_bounds__(EXACT_BLOCK) void poa_exact_kernel(ExactParams P) {
     const uint64_t qbeg = P.qoff[qi];
     const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
     const uint32_t pitch = P.pitch[qi];
-    const uint64_t RP = (uint64_t)P.G.n_rows * pitch;
     ExactWork W;
-    W.M = P.planes + P.plane_off[qi];
-    W.I = W.M + RP;
-    W.D = W.I + RP;
+    W.T = P.planes + P.plane_off[qi];
+    W.n_rows = P.G.n_rows;
     W.pitch = pitch;
     W.reached = P.reached + (uint64_t)slot * P.G.n_exit * P.wpn;
     W.rsum = P.rsum + (uint64_t)slot * P.G.n_exit * P.swpn;

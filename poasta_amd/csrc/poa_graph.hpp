@@ -22,6 +22,20 @@ enum : uint8_t {
 };
 constexpr uint32_t ROW_NEAR = 32;
 
+// Layout of the table the replayed search fills (and the traceback of that pass reads): 8 x 8-cell tiles holding the three
+// states of their cells together — [tile row][tile column][state][row & 7][offset & 7] — the dense equivalent of the
+// reference's 8 x 8 blocks (gap_affine.rs:435-446).  The search walks diagonals, rows and columns: within a tile they stay
+// in three 256-byte blocks instead of touching a new line per step.  Rows beyond the last full tile row keep the plain
+// [state][row][offset] layout in the space that is left, so the table fits the 3 * rows * pitch elements of a query.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t ex_cell_index(uint32_t row, uint32_t off, uint32_t st, uint32_t n_rows, uint32_t pitch) {
+    const uint32_t rows_t = n_rows & ~7u;
+    if (row < rows_t) return ((uint64_t)(row >> 3) * (pitch >> 3) + (off >> 3)) * 192u + st * 64u + (row & 7u) * 8u + (off & 7u);
+    return 3ull * rows_t * pitch + ((uint64_t)st * (n_rows - rows_t) + (row - rows_t)) * pitch + off;
+}
+
 struct RowMeta {  // 16 bytes, one per row
     uint32_t node;        // node index in the host graph (rpos of AlignedPair)
     uint32_t pred_begin;  // first entry in pred_rows

@@ -156,6 +156,8 @@ struct TbCtx {
     const T* D;
     const uint32_t* codes;  // compact layout: 4 flag bits per cell at the I plane's place
     uint32_t code_fmt;      // 0: nibble per cell, 1: bit-planes, 2: A, C in the M value + B, D bit-planes
+    uint32_t tiled;         // 1: the table of the replayed search (u32, ex_cell_index layout) at M
+    uint32_t n_rows;
     const uint8_t* q;
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
@@ -188,9 +190,22 @@ __host__ __device__ __forceinline__ uint32_t mf_code_stride(uint32_t pitch) { re
 __device__ __forceinline__ uint32_t mf_value(uint32_t raw) { const uint32_t v = raw & MF_MASK; return v == MF_MASK ? INF : v; }
 // the score of cell (row, j) of the M plane, whatever the format
 template <typename T>
+__device__ __forceinline__ uint32_t pl_tiled(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st) {
+    return reinterpret_cast<const uint32_t*>(c.M)[ex_cell_index(row, j, st, c.n_rows, c.pitch)];  // st: 0 M, 1 D, 2 I
+}
+template <typename T>
 __device__ __forceinline__ uint32_t plM(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    if (c.tiled) return pl_tiled(c, row, j, 0);
     if (c.code_fmt == 2) return mf_value((uint32_t)c.M[(uint64_t)row * c.pitch + j]);
     return PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t plD(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    return c.tiled ? pl_tiled(c, row, j, 1) : PlaneIO<T>::get(c.D + (uint64_t)row * c.pitch + j);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t plI(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    return c.tiled ? pl_tiled(c, row, j, 2) : PlaneIO<T>::get(c.I + (uint64_t)row * c.pitch + j);
 }
 
 template <typename T>
@@ -233,9 +248,9 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
             cs = mf_value(raw);
             code = ((raw >> 14) & 1u) | (((raw >> 15) & 1u) << 2);
         } else {
-            cs = PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j);
+            cs = plM(c, row, j);
             if (COMPACT) code = tb_code(c, row, j);
-            else { dv = pl(c.D, c.pitch, row, j); iv = pl(c.I, c.pitch, row, j); }
+            else { dv = plD(c, row, j); iv = plI(c, row, j); }
         }
         const uint32_t up = (row > 0 && j > 0) ? plM(c, row - 1, j - 1) : INF;  // the usual diagonal predecessor
         first.cs = cs;
@@ -257,7 +272,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
         if (COMPACT ? (code & 4u) != 0 : dv == cs) cand(row, j, 1);
         if (COMPACT ? (code & 1u) != 0 : iv == cs) cand(row, j, 2);
     } else if (st == 1) {
-        const uint32_t cs = COMPACT ? gap_cs : pl(c.D, c.pitch, row, j);
+        const uint32_t cs = COMPACT ? gap_cs : plD(c, row, j);
         first.cs = cs;
         if (cs == INF) return first;
         if (m.pred_count == 0) return first;
@@ -275,11 +290,11 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
         } else {
             for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
                 const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-                if (pl(c.D, c.pitch, pr, j) == t_ext) cand(pr, j, 1);  // predecessors of a non-chain row keep their D row
+                if (plD(c, pr, j) == t_ext) cand(pr, j, 1);  // predecessors of a non-chain row keep their D row
             }
         }
     } else {
-        const uint32_t cs = COMPACT ? gap_cs : pl(c.I, c.pitch, row, j);
+        const uint32_t cs = COMPACT ? gap_cs : plI(c, row, j);
         first.cs = cs;
         if (cs == INF) return first;
         if (j > 0) {
@@ -287,7 +302,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
             const uint32_t pm = plM(c, row, j - 1);
             if (pm == t_open) cand(row, j - 1, 0);
             else if (!tb_open_i(c, m, j - 1) && pm < t_open) bad = true;
-            const bool ext = COMPACT ? (tb_code(c, row, j) & 2u) != 0 : pl(c.I, c.pitch, row, j - 1) == t_ext;
+            const bool ext = COMPACT ? (tb_code(c, row, j) & 2u) != 0 : plI(c, row, j - 1) == t_ext;
             if (ext) {
                 const bool only = (n_cand == 0);
                 cand(row, j - 1, 0);  // sic: the reference returns Match here (gap_affine.rs:649)
@@ -333,6 +348,8 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     c.D = c.I + RP;
     c.codes = reinterpret_cast<const uint32_t*>(c.I);
     c.code_fmt = P.code_fmt;
+    c.tiled = P.exact_pass;  // the replayed search leaves its table tiled
+    c.n_rows = P.n_rows;
     c.start_row = P.start_row; c.end_row = P.end_row;
     c.x = P.cost_x; c.o = P.cost_o; c.e = P.cost_e;
     const uint32_t L = c.L;
@@ -375,7 +392,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
             if (!cur.found && !pn) {
                 // the end row has no insertion state (I[end] = INF) and keeps its D row in every layout
                 cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 2, INF, nc, bad, pn);  // (full planes: the stored I value is used)
-                if (!cur.found && !pn) { cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, pl(c.D, c.pitch, tb_row, tb_off), nc, bad, pn); fg = cur.cs; }
+                if (!cur.found && !pn) { cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, plD(c, tb_row, tb_off), nc, bad, pn); fg = cur.cs; }
                 // no backtrace from the end cell: the reference builds a 'simple alignment' for len <= 3 and panics otherwise
                 // (gap_affine.rs:838-853); on a replayed table that is exactly what happened, so only len > 3 is a panic
                 if (!pn) {

@@ -31,14 +31,14 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     ExactGraph G{g.n, g.start_row, g.end_row, row_sym.data(), g.succ_row_off.data(), g.succ_rows.data(),
                  g.dist_min.data(), g.dist_max.data(), g.exit_idx.data(), g.n_exit, g.nbm_off.data(), g.nbm.data(),
                  g.node_row.data(), g.sp_to_end.data()};
-    const uint32_t pitch = len + 1, wpn = (len + 1 + 63) / 64, swpn = (wpn + 63) / 64;
-    std::vector<uint32_t> M((size_t)n * pitch, EX_INF), I(M), D(M);
+    const uint32_t pitch = ((len + 1 + 63) / 64) * 64, wpn = (len + 1 + 63) / 64, swpn = (wpn + 63) / 64;  // as the engine lays it out
+    std::vector<uint32_t> T((size_t)3 * n * pitch, EX_INF);  // tiled: ex_cell_index
     std::vector<uint64_t> reached((size_t)g.n_exit * wpn + 1, 0), rsum((size_t)g.n_exit * swpn + 1, 0);
     const uint32_t n_prio = (n + len + 2) * std::max<uint32_t>(x, (uint32_t)o + e) + 2 * ((uint32_t)o + (n + len) * e) + 64;
     std::vector<uint32_t> head((size_t)3 * n_prio, EX_NIL);
-    std::vector<ExQEntry> pool((size_t)4 * n * pitch + 1024);
+    std::vector<ExQEntry> pool((size_t)4 * n * (len + 1) + 1024);
     std::vector<ExStackEntry> stack(n + len + 8);
-    ExactWork W{M.data(), I.data(), D.data(), pitch, reached.data(), rsum.data(), wpn, swpn, head.data(), n_prio,
+    ExactWork W{T.data(), g.n, pitch, reached.data(), rsum.data(), wpn, swpn, head.data(), n_prio,
                 pool.data(), (uint32_t)pool.size(), stack.data(), (uint32_t)stack.size()};
     ExactCosts EC{x, o, e, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0};
     if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
@@ -49,9 +49,11 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     if (pm) {
         for (uint32_t v = 0; v < n; ++v) {
             const uint32_t r = g.node_row[v];
-            std::memcpy(pm + (size_t)v * pitch, &M[(size_t)r * pitch], pitch * 4);
-            std::memcpy(pi + (size_t)v * pitch, &I[(size_t)r * pitch], pitch * 4);
-            std::memcpy(pd + (size_t)v * pitch, &D[(size_t)r * pitch], pitch * 4);
+            for (uint32_t j = 0; j <= len; ++j) {
+                pm[(size_t)v * (len + 1) + j] = T[ex_cell_index(r, j, EX_ST_M, g.n, pitch)];
+                pi[(size_t)v * (len + 1) + j] = T[ex_cell_index(r, j, EX_ST_I, g.n, pitch)];
+                pd[(size_t)v * (len + 1) + j] = T[ex_cell_index(r, j, EX_ST_D, g.n, pitch)];
+            }
         }
     }
     return (int)R.status;
