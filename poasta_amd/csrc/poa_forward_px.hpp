@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     const uint32_t qlE = ((c_lo > 0 && c_lo - 1 < L) ? (uint32_t)q[c_lo - 1] : 0u) | (((c_hi - 1 < L) ? (uint32_t)q[c_hi - 1] : 0u) << 16);
 
     // Symbol masks per lane, staged once in LDS: mask[s][k] = 0xFFFF per half where my query symbol equals symbol s
-    // ("ACGT"[s]; s = 4: no symbol, all zero).  A row then fetches the masks of its symbol and of its child symbol
+    // ("ACGT"[s]).  A row then fetches the masks of its symbol and of its child symbol
     // (4 ds_read_b128) instead of recomputing them (7 VALU instructions per register).  Other symbols: computed.
-    __shared__ uint4 sym_tab[4 * 5 * 2 * 64];
-    uint4* my_tab = sym_tab + (threadIdx.x >> 6) * (5 * 2 * 64) + lane;
+    __shared__ uint4 sym_tab[4 * 4 * 2 * 64];  // 32 KB per block of four waves: five blocks per CU
+    uint4* my_tab = sym_tab + (threadIdx.x >> 6) * (4 * 2 * 64) + lane;
     {
         const uint32_t letters[4] = {'A', 'C', 'G', 'T'};
 #pragma unroll
@@ -99,8 +99,6 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             my_tab[(si * 2 + 0) * 64] = make_uint4(m[0], m[1], m[2], m[3]);
             my_tab[(si * 2 + 1) * 64] = make_uint4(m[4], m[5], m[6], m[7]);
         }
-        my_tab[(4 * 2 + 0) * 64] = make_uint4(0, 0, 0, 0);
-        my_tab[(4 * 2 + 1) * 64] = make_uint4(0, 0, 0, 0);
         // each lane reads back only what it wrote itself: no barrier needed
     }
 
@@ -153,7 +151,10 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) mD[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ sym2)));
                 }
-                if (ci < 5) {
+                if (ci == 4) {  // no child symbol to spare: open everywhere
+#pragma unroll
+                    for (int k = 0; k < K; ++k) mI[k] = 0u;
+                } else if (ci < 4) {
                     const uint4 a = my_tab[(ci * 2 + 0) * 64], b = my_tab[(ci * 2 + 1) * 64];
                     mI[0] = a.x; mI[1] = a.y; mI[2] = a.z; mI[3] = a.w; mI[4] = b.x; mI[5] = b.y; mI[6] = b.z; mI[7] = b.w;
                 } else {
