@@ -544,7 +544,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 // queries longer than one strip: one workgroup per query, its strips pipelined over the waves (MW)
                 bool mw = max_pitch > 512 * quads;
                 if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
-                bool px = !mw && quads == 2 && !fuse_tb;  // one strip of up to 1024 columns: the pairs-across-quads kernel
+                bool px = max_pitch <= 1024 && quads == 2 && !fuse_tb;  // one strip of up to 1024 columns: the pairs-across-quads kernel
                 if (const char* xv = getenv("POA_PX")) px = px && atoi(xv) != 0;
                 if (px) {
                     // scores below 0x3FFF (same bound as for u16, one power lower): two flags ride in the stored M value
