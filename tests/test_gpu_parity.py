@@ -148,6 +148,36 @@ def test_one_strip_kernel_shapes(engine, oracle):
     _check_against_astar(oracle, poa.graph, qs, res)
 
 
+def test_symbols_beyond_acgt(engine, oracle):
+    """Graph and reads over A C G T N a c g t (and a few IUPAC codes): the one-strip kernel fetches the masks of A/C/G/T
+    rows from its LDS tables and computes the others; symbols are compared as bytes, exactly as the reference does."""
+    rng = np.random.default_rng(21)
+    alpha = np.frombuffer(b"ACGTNacgtRYKM", np.uint8)
+    probs = np.array([6, 6, 6, 6, 2, 1, 1, 1, 1, .5, .5, .5, .5]); probs = probs / probs.sum()
+    backbone = rng.choice(alpha, 820, p=probs)
+    b = GraphBuilder()
+    ids = b.add_path(backbone)
+    for _ in range(40):                                   # SNP-like side branches and skip edges
+        i = int(rng.integers(1, 800))
+        v = b.add_node(int(rng.choice(alpha, p=probs)))
+        b.add_edge(ids[i - 1], v); b.add_edge(v, ids[i + 1])
+        j = int(rng.integers(1, 790))
+        b.add_edge(ids[j], ids[j + int(rng.integers(2, 6))])
+    g = b.finish()
+    qs = []
+    for k in range(8):
+        q = backbone.copy()
+        pos = rng.choice(len(q), 40, replace=False)
+        q[pos] = rng.choice(alpha, 40, p=probs)
+        cut = sorted(rng.choice(len(q), 2, replace=False))
+        qs.append(np.concatenate([q[:cut[0]], q[cut[0] + int(rng.integers(0, 4)):]])[:int(rng.integers(530, 820))])
+    qs.append(backbone[:300].copy())                       # short: the 512-column kernel in its own batch below
+    for costs in ((4, 6, 2), (3, 9, 1)):
+        res, _ = _check_against_dense(engine, oracle, g, qs, costs=costs)
+        _check_against_astar(oracle, g, qs, res, costs=costs, heuristic=oracle.H_DIJKSTRA, pruning=False)
+    res, _ = _check_against_dense(engine, oracle, g, qs[-1:])
+
+
 def test_multi_wave_pipeline(engine, oracle):
     """Long queries run one workgroup per query with the strips pipelined over its waves: mixed lengths in one launch
     (waves beyond a query's last strip exit early), more strips than waves (a second group through the carry array),
