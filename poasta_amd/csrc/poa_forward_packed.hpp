@@ -141,8 +141,11 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
             qlE[m] = ((c0 > 0 && c0 - 1 < L) ? (uint32_t)q[c0 - 1] : 0u) << 16;
         }
         uint32_t Mprev[NP], Dprev[NP];
+        uint32_t PMc[NP], PDc[NP], PMlc[Q];  // predecessor minima of the last multi-predecessor row (ROW_SAME_PREDS reuses them)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) { Mprev[p] = inf2; Dprev[p] = inf2; }
+        for (int p = 0; p < NP; ++p) { Mprev[p] = inf2; Dprev[p] = inf2; PMc[p] = inf2; PDc[p] = inf2; }
+#pragma unroll
+        for (int m = 0; m < Q; ++m) PMlc[m] = inf2;
 
         for (uint32_t r = 0; r < P.n_rows; ++r) {
             const RowMeta meta = P.rows[r];
@@ -288,8 +291,14 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                     edge = (uint32_t)__builtin_amdgcn_readlane((int)Mprev[4 * m + 3], 63);
                 }
                 row_body(Mprev, Dprev);
+            } else if (meta.flags & ROW_SAME_PREDS) {
+                // a sibling of the previous row (same predecessor set): its predecessor minima are still in registers
+#pragma unroll
+                for (int m = 0; m < Q; ++m) PMl[m] = PMlc[m];
+                row_body(PMc, PDc);
             } else {
-                uint32_t PM[NP], PD[NP];
+                uint32_t (&PM)[NP] = PMc;
+                uint32_t (&PD)[NP] = PDc;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { PM[p] = inf2; PD[p] = inf2; }
 #pragma unroll
@@ -355,6 +364,8 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                         for (int p = 0; p < NP; ++p) { PM[p] = pk_min(PM[p], tm[p]); PD[p] = pk_min(PD[p], td[p]); }
                     }
                 }
+#pragma unroll
+                for (int m = 0; m < Q; ++m) PMlc[m] = PMl[m];
                 row_body(PM, PD);
             }
             m_edge_prev = in_mlast;

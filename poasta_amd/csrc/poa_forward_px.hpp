@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     const CRowWords* crows = (const CRowWords*)P.rows;
     const CU32* cpred = (const CU32*)P.pred_rows;
 
+    // predecessor minima of the last multi-predecessor row: sibling rows (ROW_SAME_PREDS) reuse them
+    uint32_t PMc[K], PDc[K], PMlc = INF2;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { PMc[k] = INF2; PDc[k] = INF2; }
+
     // one row: reads the previous row from (Mprev, Dprev), leaves this row in (Mout, Dout) — the caller alternates two
     // register sets so that no row ends with 16 register copies
     auto do_row = [&](const uint32_t r, const uint32_t (&Mprev)[K], const uint32_t (&Dprev)[K], uint32_t (&Mout)[K], uint32_t (&Dout)[K]) {
@@ -236,8 +241,12 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
         if (meta.flags & ROW_CHAIN) {
             PMl = shr_lane(Mprev[K - 1]);
             row_body(Mprev, Dprev);
+        } else if (meta.flags & ROW_SAME_PREDS) {
+            PMl = PMlc;
+            row_body(PMc, PDc);
         } else {
-            uint32_t PM[K], PD[K];
+            uint32_t (&PM)[K] = PMc;
+            uint32_t (&PD)[K] = PDc;
 #pragma unroll
             for (int k = 0; k < K; ++k) { PM[k] = INF2; PD[k] = INF2; }
             if (meta.pred_count > 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // I read back rows this wave stored
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) { PM[k] = pk_min(PM[k], tm[k]); PD[k] = pk_min(PD[k], td[k]); }
             }
+            PMlc = PMl;
             row_body(PM, PD);
         }
     };
@@ -362,6 +372,11 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
             qP[k] = a | (b << 16);
         }
         const uint32_t qlE = ((c_lo > 0 && c_lo - 1 < L) ? (uint32_t)q[c_lo - 1] : 0u) | (((c_hi - 1 < L) ? (uint32_t)q[c_hi - 1] : 0u) << 16);
+
+        // predecessor minima of the last multi-predecessor row: sibling rows (ROW_SAME_PREDS) reuse them
+        uint32_t PMc[K], PDc[K], PMlc = INF2;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { PMc[k] = INF2; PDc[k] = INF2; }
 
         auto do_row = [&](const uint32_t r, const uint32_t (&Mprev)[K], const uint32_t (&Dprev)[K], uint32_t (&Mout)[K], uint32_t (&Dout)[K]) {
             const poa_u32x4 mw = crows[r];
@@ -475,8 +490,12 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                 else if (from_global) edge = (uint32_t)Mp[(uint64_t)(r - 1) * pitch + sbase - 1];
                 PMl = shr_lane(Mprev[K - 1], edge);
                 row_body(Mprev, Dprev);
+            } else if (meta.flags & ROW_SAME_PREDS) {
+                PMl = PMlc;
+                row_body(PMc, PDc);
             } else {
-                uint32_t PM[K], PD[K];
+                uint32_t (&PM)[K] = PMc;
+                uint32_t (&PD)[K] = PDc;
 #pragma unroll
                 for (int k = 0; k < K; ++k) { PM[k] = INF2; PD[k] = INF2; }
                 if (meta.flags & ROW_FAR_PRED) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -513,6 +532,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) { PM[k] = pk_min(PM[k], tm[k]); PD[k] = pk_min(PD[k], td[k]); }
                 }
+                PMlc = PMl;
                 row_body(PM, PD);
             }
 

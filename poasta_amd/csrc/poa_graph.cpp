@@ -138,6 +138,17 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
             m.sym_idx = (uint8_t)(idx(m.sym) | (ci << 4));
         }
     }
+    // sibling rows: a non-chain row whose predecessor SET equals the previous row's
+    for (uint32_t r = 1; r < n; ++r) {
+        RowMeta& m = g.rows[r];
+        const RowMeta& p = g.rows[r - 1];
+        if ((m.flags | p.flags) & (ROW_CHAIN | ROW_END | ROW_START)) continue;
+        if (m.pred_count == 0 || m.pred_count != p.pred_count) continue;
+        std::vector<uint32_t> a(g.pred_rows.begin() + m.pred_begin, g.pred_rows.begin() + m.pred_begin + m.pred_count);
+        std::vector<uint32_t> b(g.pred_rows.begin() + p.pred_begin, g.pred_rows.begin() + p.pred_begin + p.pred_count);
+        std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+        if (a == b) m.flags |= ROW_SAME_PREDS;
+    }
     // D rows that must stay in memory for the compact plane layout: a row whose D some successor reads back
     // (forward pass: non-adjacent predecessor; traceback: any predecessor of a non-chain row), plus the end row.
     for (uint32_t r = 0; r < n; ++r) {

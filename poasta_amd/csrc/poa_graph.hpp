@@ -19,6 +19,8 @@ enum : uint8_t {
     ROW_CHAIN = 16,        // exactly one predecessor and it is the previous row
     ROW_STORE_D = 32,      // some successor reads this row's D from memory (it is not a chain row right below): keep the D row
     ROW_FAR_PRED = 64,     // some predecessor lies more than ROW_NEAR rows back (multi-wave kernel: beyond the hand-over ring)
+    ROW_SAME_PREDS = 128,  // same predecessor set as the previous row (sibling nodes of a bubble / an MSA column): the
+                           // predecessor minima of the previous row can be reused
 };
 constexpr uint32_t ROW_NEAR = 32;
 
