@@ -263,9 +263,16 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
             if ((m.flags & ROW_CHAIN) && !is_end) {  // the end row reads its predecessor at the SAME column
                 if (up == target) cand(row - 1, pj, 0);
             } else {
-                for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-                    const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-                    if (plM(c, pr, pj) == target) cand(pr, pj, 0);
+                // predecessors four at a time: the row indices, then their scores, then the tests in trait order
+                for (uint32_t pe0 = 0; pe0 < m.pred_count; pe0 += 4) {
+                    uint32_t prs[4], vals[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) prs[b] = (pe0 + b < m.pred_count) ? c.pred_rows[m.pred_begin + pe0 + b] : 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) vals[b] = (pe0 + b < m.pred_count) ? plM(c, prs[b], pj) : INF;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (pe0 + b < m.pred_count && vals[b] == target) cand(prs[b], pj, 0);
                 }
             }
         }
@@ -278,19 +285,32 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
         if (m.pred_count == 0) return first;
         const uint32_t t_open = sub(sub(cs, c.o), c.e), t_ext = sub(cs, c.e);
         const bool real_open = !is_end && (j >= c.L || (uint32_t)m.sym != (uint32_t)c.q[j]);
-        for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-            const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-            const uint32_t ps = plM(c, pr, j);
-            if (ps == t_open) cand(pr, j, 0);
-            else if (!real_open && ps < t_open) bad = true;  // phantom edge the reference does not re-check
+        for (uint32_t pe0 = 0; pe0 < m.pred_count; pe0 += 4) {
+            uint32_t prs[4], vals[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) prs[b] = (pe0 + b < m.pred_count) ? c.pred_rows[m.pred_begin + pe0 + b] : 0u;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) vals[b] = (pe0 + b < m.pred_count) ? plM(c, prs[b], j) : INF;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (pe0 + b >= m.pred_count) continue;
+                if (vals[b] == t_open) cand(prs[b], j, 0);
+                else if (!real_open && vals[b] < t_open) bad = true;  // phantom edge the reference does not re-check
+            }
         }
         if (COMPACT && (m.flags & ROW_CHAIN)) {
             // single predecessor right above: D[row][j] == D[row-1][j] + e is code bit 3
             if (tb_code(c, row, j) & 8u) cand(row - 1, j, 1);
         } else {
-            for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
-                const uint32_t pr = c.pred_rows[m.pred_begin + pe];
-                if (plD(c, pr, j) == t_ext) cand(pr, j, 1);  // predecessors of a non-chain row keep their D row
+            for (uint32_t pe0 = 0; pe0 < m.pred_count; pe0 += 4) {
+                uint32_t prs[4], vals[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) prs[b] = (pe0 + b < m.pred_count) ? c.pred_rows[m.pred_begin + pe0 + b] : 0u;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) vals[b] = (pe0 + b < m.pred_count) ? plD(c, prs[b], j) : INF;  // predecessors of a non-chain row keep their D row
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (pe0 + b < m.pred_count && vals[b] == t_ext) cand(prs[b], j, 1);
             }
         }
     } else {
