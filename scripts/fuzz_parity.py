@@ -116,4 +116,6 @@ for seed in range(args.first, args.first + args.seeds):
                 sys.exit(1)
             n_exact += 1
     n_cases += 1
+    if n_cases % 100 == 0:  # keeps a long run visibly alive
+        print(json.dumps(dict(progress=n_cases, seconds=round(time.time() - t0, 1))), flush=True)
 print(json.dumps(dict(ok=True, graphs=n_cases, dense_queries=n_dense, exact_queries=n_exact, seconds=round(time.time() - t0, 1))))
