@@ -5,9 +5,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <new>
 #include <mutex>
@@ -37,16 +39,67 @@ int fail(int code, const std::string& msg) {
             return fail(POA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
     } while (0)
 
+// Device buffers come from a small per-device cache of released blocks: a host that calls poa_align_batch once per
+// batch of reads would otherwise spend more time in hipMalloc / hipFree (measured 12 ms per call for the ~15 buffers of
+// a config-2 batch) than in the kernels.  poa_release_cache() returns everything to the driver.
+struct BufCache {
+    static constexpr size_t kMaxCachedBytes = 8ull << 30;  // per device, not counting the plane workspace
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks[16];
+    size_t cached_bytes[16] = {};
+    void* take(int dev, size_t need, size_t* got) {
+        if (dev < 0 || dev >= 16) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = free_blocks[dev].lower_bound(need);
+        if (it == free_blocks[dev].end() || it->first > 2 * need + (1u << 20)) return nullptr;
+        void* p = it->second;
+        *got = it->first;
+        cached_bytes[dev] -= it->first;
+        free_blocks[dev].erase(it);
+        return p;
+    }
+    bool give(int dev, void* p, size_t bytes) {
+        if (dev < 0 || dev >= 16) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (cached_bytes[dev] + bytes > kMaxCachedBytes) return false;
+        free_blocks[dev].emplace(bytes, p);
+        cached_bytes[dev] += bytes;
+        return true;
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int d = 0; d < 16; ++d) {
+            if (free_blocks[d].empty()) continue;
+            (void)hipSetDevice(d);
+            for (auto& kv : free_blocks[d]) (void)hipFree(kv.second);
+            free_blocks[d].clear();
+            cached_bytes[d] = 0;
+        }
+    }
+};
+static BufCache g_buf_cache;
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t cap_bytes = 0;
+    int dev = -1;
+    ~DevBuf() { drop(); }
+    void drop() {
+        if (!p) return;
+        if (!g_buf_cache.give(dev, p, cap_bytes)) { (void)hipSetDevice(dev); (void)hipFree(p); }
+        p = nullptr; cap_bytes = 0;
+    }
     hipError_t alloc(size_t count) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+        drop();
         n = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void**)&p, count * sizeof(T));
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        const size_t need = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (void* c = g_buf_cache.take(dev, need, &cap_bytes)) { p = (T*)c; return hipSuccess; }
+        cap_bytes = need;
+        return hipMalloc((void**)&p, need);
     }
 };
 }  // namespace
@@ -844,16 +897,24 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
                 ws_hint = elems * 2;
         }
     }
+    const bool timing = getenv("POA_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     poa_batch_t* b = nullptr;
     int rc = poa_batch_create(g, device, n_queries, qseq, qoff, ws_hint, &b);
     if (rc != POA_OK) return rc;
+    const double t1 = now();
     rc = poa_batch_run_ex(b, costs, cfg, nullptr);
+    const double t2 = now();
     if (rc == POA_OK) rc = poa_batch_fetch(b, score, pairs, pair_off, pair_capacity, flags, stats);
+    const double t3 = now();
     poa_batch_destroy(b);
+    if (timing) std::fprintf(stderr, "poa_align_batch: create %.2f ms, launch %.2f ms, fetch (sync + copies) %.2f ms, destroy %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
     return rc;
 }
 
 void poa_release_cache(void) {
+    g_buf_cache.release_all();
     std::lock_guard<std::mutex> lk(g_ws_cache.mu);
     for (int d = 0; d < 16; ++d) {
         if (!g_ws_cache.p[d]) continue;
