@@ -258,6 +258,13 @@ static void collect_stats(poa_batch* b, poa_stats_t* stats) {
 
 // the 1024-column multi-wave kernel when the chunk fills the chip with one wave per 1024 columns (else 512-column strips of
 // the adjacent-pairs kernel give twice the waves)
+// waves per workgroup of a multi-wave launch: all strips at once when they fit, else the strips spread evenly over the
+// groups that run one after the other (16 + 4 strips would leave twelve waves idle in the second group)
+static uint32_t mw_waves(uint32_t strips) {
+    const uint32_t groups = (strips + MW_MAX_WAVES - 1) / MW_MAX_WAVES;
+    return (strips + groups - 1) / groups;
+}
+
 static bool pxmw_ok(uint32_t count, uint32_t max_pitch) {
     if (const char* v = getenv("POA_PXMW")) return atoi(v) != 0;
     return (uint64_t)count * ((max_pitch + 1023) / 1024) >= 1024;
@@ -609,13 +616,13 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 } else if (mw && pxmw_ok(ch.count, max_pitch)) {
                     // pairs-across-quads mapping, 1024-column strips pipelined over the waves of a workgroup
                     tp.code_fmt = 1;
-                    const uint32_t waves = std::min<uint32_t>((max_pitch + 1023) / 1024, MW_MAX_WAVES);
+                    const uint32_t waves = mw_waves((max_pitch + 1023) / 1024);
                     hipLaunchKernelGGL(poa_forward_pxmw_kernel, dim3(ch.count), dim3(64 * waves), 0, stream, fp);
                 } else if (mw) {
                     // narrow strips (more waves) until the chunk alone fills the chip
                     if (!quads_override) quads = ((uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192) ? 2 : 1;
                     const uint32_t strips = (max_pitch + 512 * quads - 1) / (512 * quads);
-                    const uint32_t waves = std::min<uint32_t>(strips, MW_MAX_WAVES);
+                    const uint32_t waves = mw_waves(strips);
                     if (quads == 1) hipLaunchKernelGGL((poa_forward_packed_kernel<1, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
                     else hipLaunchKernelGGL((poa_forward_packed_kernel<2, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
                 } else if (quads == 1) {
@@ -636,13 +643,20 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             bool mw = max_pitch > 1024;  // longer than the widest strip: pipeline the strips over the waves of a workgroup
             if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
             if (mw) {
-                // 512-column strips (up to 16 waves per query) until the chunk alone fills the chip, else 1024 (up to 10)
-                const bool wide = quads_override == 4 || (!quads_override && (uint64_t)ch.count * ((max_pitch + 1023) / 1024) >= 8192);
+                // 512-column strips (up to 16 waves per query) or 1024-column ones (up to 10): a query whose strips do not all
+                // fit one workgroup runs as several groups one after the other, and few long queries are latency bound per
+                // row (a 1024-column row costs ~1.4x a 512-column one), so take the variant with the least groups x row cost;
+                // the waves per workgroup are balanced over the groups
+                const uint32_t s2 = (max_pitch + 511) / 512, s4 = (max_pitch + 1023) / 1024;
+                const uint32_t g2 = (s2 + MW_MAX_WAVES - 1) / MW_MAX_WAVES, g4 = (s4 + 9) / 10;
+                bool wide = 14 * g4 < 10 * g2 || (uint64_t)ch.count * s4 >= 8192;
+                if (quads_override == 4) wide = true;
+                if (quads_override == 2) wide = false;
                 if (wide) {
-                    const uint32_t waves = std::min<uint32_t>((max_pitch + 1023) / 1024, 10);
+                    const uint32_t waves = (s4 + g4 - 1) / g4;
                     hipLaunchKernelGGL((poa_forward_kernel<4, uint32_t, false, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
                 } else {
-                    const uint32_t waves = std::min<uint32_t>((max_pitch + 511) / 512, MW_MAX_WAVES);
+                    const uint32_t waves = (s2 + g2 - 1) / g2;
                     hipLaunchKernelGGL((poa_forward_kernel<2, uint32_t, false, false, true>), dim3(ch.count), dim3(64 * waves), 0, stream, fp, tp);
                 }
             } else if (quads == 1) LAUNCH_FWD(1, uint32_t);
