@@ -180,7 +180,9 @@ def main():
                          "traceback_ms_per_step": round(st["ms_traceback"] / max(st["n_runs"], 1), 3)},
         }
         if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(graph, qs[:min(args.cpu_sample, len(qs))], n_rows)
+            sample = qs[:min(args.cpu_sample, len(qs))]
+            line["cpu_baseline"], A = cpu_baseline(graph, sample, n_rows)
+            line["bit_exact_check"] = bit_exact_check(graph, sample, res, A, costs)
         print(json.dumps(line), flush=True)
     batch.close()
     if dist is not None:
@@ -201,13 +203,36 @@ def cpu_baseline(graph, qs, n_rows):
                        want_pairs=True, want_counters=True)
     dt = time.perf_counter() - t0
     cells = sum(n_rows * (int(qoff[i + 1] - qoff[i]) + 1) for i in range(len(qs)))
-    return {"value": round(cells / dt / 1e9, 4), "unit": "Gcells/s (matrix-equivalent)", "cores": threads,
+    return ({"value": round(cells / dt / 1e9, 4), "unit": "Gcells/s (matrix-equivalent)", "cores": threads,
             "kind": "port",
             "sample": "%d queries of the same workload, A* + min-gap heuristic + superbubble pruning + backtrace "
                       "(C++ restatement of the reference CPU path), %d threads, %.2f s wall" % (len(qs), threads, dt),
             "aligned_bases_per_sec": round(int(qoff[-1]) / dt, 1),
             "visited_states_per_sec": round(float(A["counters"][:, 1].sum()) / dt, 1),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count()}, A)
+
+
+def bit_exact_check(graph, qs, dense_res, A, costs):
+    """Outside the timed region: the same sample against the restated reference — scores of the timed dense pass, and
+    alignments of the hybrid mode (dense pass + replay of the reference's search where the dense pass found ties)."""
+    from oracle import pyoracle
+    from poasta_amd import aligner
+    n = len(qs)
+    ok = A["status"] == 0
+    score_equal = int(sum(1 for i in range(n) if ok[i] and int(dense_res.score[i]) == int(A["score"][i])))
+    dense_identical = int(sum(1 for i in range(n) if ok[i] and dense_res.raw_alignment(i) == pyoracle.batch_alignment(A, i)))
+    k = min(n, 512)
+    al = aligner.PoastaAligner(aligner.AffineMinGapCost(costs), mode="hybrid")
+    al.align_batch(graph, qs[:8])  # warm (replay workspace)
+    t0 = time.perf_counter()
+    hy = al.align_batch(graph, qs[:k])
+    dt = time.perf_counter() - t0
+    hybrid_identical = int(sum(1 for i in range(k) if ok[i] and int(hy.score[i]) == int(A["score"][i]) and
+                               hy.raw_alignment(i) == pyoracle.batch_alignment(A, i)))
+    return {"against": "restated reference (A*, min-gap, pruning), %d queries" % n, "dense_scores_equal": score_equal,
+            "dense_alignments_identical": dense_identical, "dense_flagged_as_tied": int((dense_res.flags[:n] != 0).sum()),
+            "hybrid_queries": k, "hybrid_alignments_identical": hybrid_identical, "hybrid_seconds": round(dt, 3),
+            "hybrid_replayed": int(hy.stats["n_exact"])}
 
 
 if __name__ == "__main__":
