@@ -17,6 +17,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -47,6 +48,8 @@ struct Graph {
     std::vector<uint32_t> seq_start_nodes;  // Sequence(name, start_node), poa.rs:21
     std::vector<std::string> seq_names;
     std::vector<uint32_t> topo;  // topological_sorted (node ids in order)
+    // POAEdgeData::sequence_ids (poa.rs:58-62), keyed by (source << 32 | target); start/end edges carry none (poa.rs:73-78)
+    std::map<uint64_t, std::vector<uint32_t>> edge_seq_ids;
 
     size_t node_count_with_start_and_end() const { return symbol.size(); }
 
@@ -66,11 +69,13 @@ struct Graph {
         succ[s].insert(succ[s].begin(), t);
         pred[t].insert(pred[t].begin(), s);
     }
-    // POAGraph::add_edge (poa.rs:118-134): an existing edge keeps its position.
-    void poa_add_edge(uint32_t s, uint32_t t) {
+    // POAGraph::add_edge (poa.rs:118-134): an existing edge keeps its position and gets the sequence id appended.
+    void poa_add_edge(uint32_t s, uint32_t t, uint32_t sequence_id) {
         if (!has_edge(s, t)) raw_add_edge(s, t);
+        edge_seq_ids[((uint64_t)s << 32) | t].push_back(sequence_id);
     }
     void remove_edge(uint32_t s, uint32_t t) {
+        edge_seq_ids.erase(((uint64_t)s << 32) | t);
         auto& a = succ[s];
         a.erase(std::find(a.begin(), a.end(), t));
         auto& b = pred[t];
@@ -101,7 +106,7 @@ struct Graph {
         for (size_t pos = start_pos; pos < end_pos; ++pos) {
             uint32_t curr = add_node(seq[pos]);
             if (!have_first) { first = curr; have_first = true; }
-            if (have_prev) poa_add_edge(prev, curr);
+            if (have_prev) poa_add_edge(prev, curr, (uint32_t)n_sequences);
             prev = curr; have_prev = true;
         }
         last = prev;
@@ -171,10 +176,10 @@ struct Graph {
                 curr = add_node(qsym);
             }
             if (!have_begin) { begin_first = curr; have_begin = true; }
-            if (have_prev) poa_add_edge(prev, curr);
+            if (have_prev) poa_add_edge(prev, curr, (uint32_t)n_sequences);
             prev = curr; have_prev = true;
         }
-        if (have_end) poa_add_edge(prev, e1);
+        if (have_end) poa_add_edge(prev, e1, (uint32_t)n_sequences);
         seq_start_nodes.push_back(begin_first); seq_names.push_back(name); n_sequences++;
         post_process();
         return 0;

@@ -13,6 +13,7 @@
 #include "bubbles.hpp"
 #include "dense.hpp"
 #include "graph.hpp"
+#include "msa.hpp"
 
 using namespace poa_oracle;
 
@@ -330,6 +331,30 @@ int oracle_dense_batch(void* p, uint8_t m, uint8_t o, uint8_t e, uint32_t n_quer
         }
         return 0;
     } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
+// poa_graph_to_fasta (src/io/fasta.rs:69-156): returns the byte length (the text is truncated to cap-1 bytes)
+int64_t oracle_poa_to_fasta(void* p, char* buf, uint64_t cap) {
+    try {
+        std::string s = poa_graph_to_fasta(((GraphHandle*)p)->g);
+        size_t k = std::min<size_t>(s.size(), cap ? cap - 1 : 0);
+        if (cap) { std::memcpy(buf, s.data(), k); buf[k] = 0; }
+        return (int64_t)s.size();
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+// load_graph_from_fasta_msa (src/io/graph.rs:36-103): names / rows are '\n'-separated lists
+void* oracle_poa_from_msa(const char* names, const char* rows) {
+    try {
+        auto split = [](const char* t) {
+            std::vector<std::string> out; std::string cur;
+            for (const char* c = t; *c; ++c) { if (*c == '\n') { out.push_back(cur); cur.clear(); } else cur.push_back(*c); }
+            out.push_back(cur);
+            return out;
+        };
+        auto* h = new GraphHandle;
+        h->g = load_graph_from_fasta_msa(split(names), split(rows));
+        return h;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return nullptr; }
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ DF_AMBIGUOUS, DF_START_QUIRK, DF_REF_PANIC, DF_SHORT_QUERY, DF_TRUNCATED = 1, 2,
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_c.cpp", "graph.hpp", "bubbles.hpp", "astar.hpp", "dense.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
     if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libpoa_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -78,6 +78,10 @@ def lib():
         L.oracle_dense_align.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
         L.oracle_dense_batch.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         L.oracle_set_alignment_type.argtypes = [vp]
+        L.oracle_poa_to_fasta.restype = C.c_int64
+        L.oracle_poa_to_fasta.argtypes = [vp, C.c_char_p, C.c_uint64]
+        L.oracle_poa_from_msa.restype = vp
+        L.oracle_poa_from_msa.argtypes = [C.c_char_p, C.c_char_p]
         L.oracle_is_end.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
         _lib = L
     return _lib
@@ -168,6 +172,22 @@ class OracleGraph:
         return cls(lib().oracle_graph_from_csr(int(csr["n"]), int(csr["start"]), int(csr["end"]), _p(a["symbol"]),
                                                _p(a["succ_off"]), _p(a["succ"]), _p(a["pred_off"]), _p(a["pred"]),
                                                1 if end_matches_all else 0))
+
+    @classmethod
+    def from_fasta_msa(cls, records):
+        """load_graph_from_fasta_msa (src/io/graph.rs:36-103); records = [(name, gapped row), ...]."""
+        names = "\n".join(n for n, _ in records).encode()
+        rows = "\n".join(r for _, r in records).encode()
+        return cls(lib().oracle_poa_from_msa(names, rows))
+
+    def to_fasta(self):
+        """poa_graph_to_fasta (src/io/fasta.rs:69-156) as text."""
+        k = lib().oracle_poa_to_fasta(self.h, None, 0)
+        if k < 0:
+            raise RuntimeError(lib().oracle_last_error().decode())
+        buf = C.create_string_buffer(int(k) + 1)
+        lib().oracle_poa_to_fasta(self.h, buf, int(k) + 1)
+        return buf.value.decode()
 
     # -- accessors --
     @property
@@ -320,6 +340,35 @@ class OracleGraph:
         if rc != 0:
             raise RuntimeError(lib().oracle_last_error().decode())
         return dict(score=scores, pairs=pairs, pair_off=pair_off, n_pairs=npairs, flags=flags)
+
+
+def read_fasta(path):
+    """[(name, sequence)] of a FASTA file (multi-line records joined; name = first word of the header)."""
+    recs = []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                recs.append([line[1:].split()[0] if line[1:].split() else "", ""])
+            elif recs:
+                recs[-1][1] += line.strip()
+    return [(n, s) for n, s in recs]
+
+
+def sequential_poa(records, costs=None, heuristic=H_MINGAP, prune=True, graph=None):
+    """`poasta align` (src/bin/poasta.rs:163-236): the first read seeds the graph, every other read is aligned
+    (Global) and added with add_alignment_with_weights.  Returns (graph, [score per aligned read])."""
+    costs = costs or Costs()
+    g = graph or OracleGraph.new_poa()
+    scores = []
+    for name, seq in records:
+        if g.n == 2:  # graph.is_empty()
+            g.add_alignment(name, seq, None)
+        else:
+            r = g.astar_align(seq, costs, heuristic, prune)
+            scores.append(r["score"])
+            g.add_alignment(name, seq, r["alignment"])
+    return g, scores
 
 
 class RefPanic(RuntimeError):
