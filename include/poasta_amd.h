@@ -190,6 +190,10 @@ int poa_batch_stats(poa_batch_t* b, poa_stats_t* stats);
 /* device pointers of the results of the last run (valid until the next run / destroy):
  * score u32[n], flags u32[n], pair_off u64[n+1], pairs poa_aln_pair_t[pair_off[n]] */
 int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** pair_off, void** pairs);
+/* AstarResult::{num_queued, num_visited, num_pruned} (src/aligner/astar.rs:81-90) of the queries whose result came from the
+ * replayed search in the last exact / hybrid run, plus the number of steps the wave search took: out[4 * n], one
+ * {num_queued, num_visited, num_pruned, steps} per query (zeros for queries that were not replayed). */
+int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out);
 /* debugging / parity: copy the M, I, D score planes of query i (rows x (len+1), row = topological
  * rank, see poa_graph_node_rows) — only valid if the query's chunk was the last one run */
 int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t* i, uint32_t* d);

@@ -242,6 +242,12 @@ class ResidentBatch:
         _lib.check(_lib.lib().poa_batch_stats(self.handle, C.byref(st)))
         return st.as_dict()
 
+    def search_counters(self):
+        """AstarResult::{num_queued, num_visited, num_pruned} + wave-search steps, one row per query (exact / hybrid runs)."""
+        out = np.zeros((self.n, 4), np.uint32)
+        _lib.check(_lib.lib().poa_batch_fetch_search_counters(self.handle, _p(out)))
+        return out
+
     def device_results(self):
         ptrs = [C.c_void_p() for _ in range(4)]
         _lib.check(_lib.lib().poa_batch_device_results(self.handle, *[C.byref(p) for p in ptrs]))

@@ -19,6 +19,7 @@
 #include "../../include/poasta_amd.h"
 #include "poa_graph.hpp"
 #include "poa_exact_kernel.hpp"
+#include "poa_wsearch.hpp"
 #include "poa_kernels.hpp"
 #include "poa_forward_packed.hpp"
 #include "poa_forward_px.hpp"
@@ -201,6 +202,9 @@ struct poa_batch {
     DevBuf<ExQEntry> d_ex_pool;
     DevBuf<ExStackEntry> d_ex_stack;
     uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0, ex_swpn = 0;
+    uint32_t ex_win = 64;              // wave search: priorities in the descriptor ring (power of two)
+    uint32_t ex_skew = 0;              // max over nodes of dist_to_end max - min: bounds how far the min-gap heuristic can grow along a greedy extension
+    DevBuf<uint32_t> d_ex_counters;    // wave search: num_queued, num_visited, num_pruned, steps per query
     bool exact_ready = false;
     uint32_t last_mode = 0;
 
@@ -442,13 +446,29 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     int rc = build_bubble_index(const_cast<FlatGraph&>(fg), err);
     if (rc != POA_OK) return fail(rc, err);
     const uint32_t n = fg.n;
+    {
+        // spread of the path lengths to the end: bounds how far the min-gap heuristic can grow along a greedy extension
+        // (heuristic.rs:70-102), hence the priority range the wave search keeps live at once (its descriptor ring)
+        uint32_t skew = 0;
+        for (uint32_t r = 0; r < n; ++r) skew = std::max<uint32_t>(skew, fg.dist_max[r] - std::min(fg.dist_min[r], fg.dist_max[r]));
+        b->ex_skew = skew;
+    }
     const uint32_t maxc = std::max<uint32_t>(costs->mismatch, (uint32_t)costs->gap_open + costs->gap_extend);
     const uint64_t n_prio64 = ((uint64_t)n + b->max_len + 2) * maxc + costs->gap_open + ((uint64_t)n + b->max_len) * costs->gap_extend + 64;
     if (n_prio64 > (1ull << 26)) return fail(POA_ERR_UNSUPPORTED, "exact replay: priority range too large for this graph / query size");
     const float f = (cfg && cfg->queue_entries_per_cell > 0.f) ? cfg->queue_entries_per_cell : 0.25f;
     const uint64_t pool64 = std::max<uint64_t>(256, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
     if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
-    const uint32_t n_prio = (uint32_t)n_prio64, pool_cap = (uint32_t)pool64;
+    // wave search: the descriptor ring covers `win` priorities (see the launch), and every live stack holds a chunk of its own
+    uint32_t win = 64;
+    {
+        const uint64_t win_need = (uint64_t)maxc + costs->gap_open + ((uint64_t)b->ex_skew + 3) * costs->gap_extend + 8;
+        while (win < win_need && win < (1u << 24)) win *= 2;
+    }
+    const uint64_t pool_ws = pool64 + (uint64_t)BQ_CHUNK * (3ull * win + 8);
+    if (pool_ws > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
+    const uint32_t n_prio = (uint32_t)n_prio64, pool_cap = (uint32_t)pool_ws;
+    b->ex_win = win;
     const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64), swpn = (wpn + 63) / 64;
     if (b->exact_ready && b->ex_n_prio >= n_prio && b->ex_pool_cap >= pool_cap) return POA_OK;
     const uint64_t slots = b->plan[0].max_chunk;
@@ -473,6 +493,7 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
         }
         HIP_TRY(b->d_nbm_off.alloc(n + 1)); HIP_TRY(b->d_nbm.alloc(std::max<size_t>(fg.nbm.size(), 1)));
         HIP_TRY(b->d_ex_status.alloc(std::max<uint32_t>(b->n_queries, 1)));
+        HIP_TRY(b->d_ex_counters.alloc(4 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
         HIP_TRY(hipMemcpy(b->d_succ_off.p, fg.succ_row_off.data(), fg.succ_row_off.size() * 4, hipMemcpyHostToDevice));
         if (!fg.succ_rows.empty()) HIP_TRY(hipMemcpy(b->d_succ_rows.p, fg.succ_rows.data(), fg.succ_rows.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_dist_min.p, fg.dist_min.data(), n * 4, hipMemcpyHostToDevice));
@@ -689,6 +710,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             // exact replay of the reference's search on the (re-initialised, u32) planes of this chunk
             const uint32_t hybrid = mode == POA_MODE_HYBRID ? 1u : 0u;
             HIP_TRY(hipMemsetAsync(b->d_ex_status.p + ch.first, 0xFF, (size_t)ch.count * 4, stream));
+            HIP_TRY(hipMemsetAsync(b->d_ex_counters.p + 4 * (size_t)ch.first, 0, (size_t)ch.count * 16, stream));
             hipLaunchKernelGGL(poa_fill_planes_kernel, dim3(64, ch.count), dim3(256), 0, stream, b->d_planes.p, PL.d_off.p,
                                b->d_pitch.p, fg.n, ch.first, hybrid, b->d_flags.p);
             HIP_TRY(hipGetLastError());
@@ -716,13 +738,51 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             }
             ep.status = b->d_ex_status.p;
             ep.end_cell = b->d_ex_end.p;
+            ep.n_succ = (uint32_t)fg.succ_rows.size(); ep.n_nbm = (uint32_t)fg.nbm.size();
+            // Wave-per-query search (poa_wsearch.hpp) unless its descriptor ring cannot hold the priorities that are live
+            // at once: one pop pushes at most max(x, o+e) above its own priority plus what the heuristic can jump along
+            // one edge and a state change (o), and the greedy extension walks that jump once more.
+            // live priority range: a pop at priority f pushes at most max(x, o+e) + o + e * (spread + 3) above f, where
+            // spread = max over nodes of dist_max - dist_min (the heuristic's gap length grows by at most that along any
+            // greedy extension: heuristic.rs:70-102)
+            const uint32_t win = b->ex_win;
+            int lds_cap = 64 * 1024;
+            (void)hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, b->device);
+            const uint32_t graph_lds = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
+            const char* impl = getenv("POA_EXACT_IMPL");
+            const bool wave_search = !(impl && !strcmp(impl, "lane")) && win <= b->ex_n_prio;
+            if (wave_search) {
+                WSearchParams wp;
+                wp.E = ep;
+                wp.chunks = reinterpret_cast<ExU4*>(b->d_ex_pool.p);
+                wp.chunk_cap = b->ex_pool_cap / BQ_CHUNK;
+                if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < wp.chunk_cap) wp.chunk_cap = (uint32_t)v; }
+                wp.win = win;
+                wp.counters = b->d_ex_counters.p;
+                // waves per block: as many as share one staged copy of the graph within half a CU's LDS, at most 16
+                uint32_t wpb = 16;
+                if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && v <= 16) wpb = (uint32_t)v; }
+                const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 80u * 1024u);
+                bool ring_lds = (uint64_t)wpb * win * 12 <= lds_budget;
+                if (getenv("POA_WS_RING_GLOBAL")) ring_lds = false;
+                const uint64_t ring_bytes = ring_lds ? (uint64_t)wpb * win * 12 : 0;
+                bool stage = graph_lds + ring_bytes <= lds_budget;
+                if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
+                wp.graph_lds = stage ? graph_lds : 0;
+                wp.waves_per_block = wpb;
+                wp.ring_global = nullptr;
+                if (!ring_lds) wp.ring_global = b->d_ex_head.p;  // [slots * 3 * ex_n_prio] holds slots * 3 * win
+                const uint32_t lds_bytes = wp.graph_lds + (uint32_t)ring_bytes;
+                if (lds_bytes > 48u * 1024u)
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(poa_wsearch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL(poa_wsearch_kernel, dim3((ch.count + wpb - 1) / wpb), dim3(64 * wpb), lds_bytes, stream, wp);
+            } else {
             // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
             // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.
             uint32_t lanes = (ch.count + 4095) / 4096;
             if (lanes > 64) lanes = 64;
             if (const char* lv = getenv("POA_EXACT_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
             ep.lanes_per_wave = lanes;
-            ep.n_succ = (uint32_t)fg.succ_rows.size(); ep.n_nbm = (uint32_t)fg.nbm.size();
             // graph arrays in LDS when they fit beside three other blocks of the same CU (160 KB per CU)
             uint32_t lds_bytes = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
             bool lds_graph = lds_bytes <= 160u * 1024u / 3u;
@@ -741,6 +801,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             }
             const uint32_t per_block = lanes * (EXACT_BLOCK / 64);
             hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + per_block - 1) / per_block), dim3(EXACT_BLOCK), lds_graph ? lds_bytes : 0, stream, ep);
+            }
             HIP_TRY(hipGetLastError());
             tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p; tp.ex_end = b->d_ex_end.p;
             hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
@@ -821,6 +882,16 @@ int poa_batch_stats(poa_batch_t* b, poa_stats_t* stats) {
     if (b->ran) HIP_TRY(hipStreamSynchronize(b->last_stream));
     std::memset(stats, 0, sizeof(*stats));
     collect_stats(b, stats);
+    return POA_OK;
+}
+
+int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out) {
+    if (!b || !out) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_search_counters: null argument");
+    if (!b->ran || b->last_mode == POA_MODE_DENSE || !b->d_ex_counters.p)
+        return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch_search_counters: the last run was not an exact / hybrid run");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (b->n_queries) HIP_TRY(hipMemcpy(out, b->d_ex_counters.p, (size_t)b->n_queries * 16, hipMemcpyDeviceToHost));
     return POA_OK;
 }
 

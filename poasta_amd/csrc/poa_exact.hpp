@@ -20,7 +20,9 @@
 #include "poa_graph.hpp"
 
 #if defined(__HIPCC__)
-#define POA_HD __host__ __device__
+// always inlined on the device: a call would force the search object (graph / workspace pointers, queue state) out of
+// registers into scratch memory
+#define POA_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define POA_HD
 #endif
@@ -56,6 +58,15 @@ struct ExactGraph {  // row-indexed, read-only, shared by all queries
 struct ExQEntry { uint32_t score, row, offset, next; };
 struct ExStackEntry { uint32_t row, offset, it; };
 
+// Bucket queue of the wave-per-query search (poa_wsearch.hpp): per (priority, state) a LIFO stack kept as a chain of
+// 64-slot chunks (slot 0: {previous chunk}, slots 1..63: entries), so that the top entries of a stack are contiguous and a
+// wave reads one per lane.  The (top chunk, entries in it) descriptors of the live priorities sit in a ring of `bq_win`
+// priorities (LDS on the device); a drained stack resets its descriptor, which frees the ring slot for priority + bq_win.
+struct BqDesc { uint32_t top, n_top; };  // in the ring: one word, top << 6 | n_top (0xFFFFFFFF: empty stack); chunk index < 2^26
+constexpr uint32_t BQ_EMPTY = 0xFFFFFFFFu;
+struct ExU4 { uint32_t x, y, z, w; };
+constexpr uint32_t BQ_CHUNK = 64;
+
 struct ExactWork {  // per query
     uint32_t* T;            // visited table, tiled (ex_cell_index), INF-initialised; states: EX_ST_M / EX_ST_D / EX_ST_I
     uint32_t n_rows, pitch;
@@ -66,6 +77,9 @@ struct ExactWork {  // per query
     uint32_t n_prio;
     ExQEntry* pool; uint32_t pool_cap;
     ExStackEntry* stack; uint32_t stack_cap;
+    // bucket queue (null bq_desc: the linked-list queue above)
+    uint32_t* bq_desc = nullptr; uint32_t bq_win = 0;
+    ExU4* bq_chunks = nullptr; uint32_t bq_chunk_cap = 0;
 };
 
 struct ExactResult {
@@ -85,8 +99,41 @@ struct ExactCosts {
     uint32_t gfe_kind, gfe_val;   // graph_free_end
 };
 
-class ExactSearch {
+// Address-space tags of the two tables a kernel may stage in LDS (the graph arrays; the queue's descriptor ring).  A pointer
+// that may be global or LDS compiles to FLAT loads, which wait for every outstanding vector-memory AND LDS operation
+// (they count on both counters): one such load in the middle of a batch of table reads serialises the batch.  With the
+// tag the access is a ds_read / ds_write and overlaps with the global loads in flight.
+enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2 };
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ inline __attribute__((always_inline)) T ex_lds_load(const T* p) {
+    return *(const __attribute__((address_space(3))) T*)p;
+}
+template <class T> __device__ inline __attribute__((always_inline)) void ex_lds_store(T* p, T v) {
+    *(__attribute__((address_space(3))) T*)p = v;
+}
+#endif
+
+template <int AS = 0>
+class ExactSearchT {
 public:
+    template <class T> POA_HD T gld(const T* p) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((AS & EX_AS_GRAPH_LDS) != 0) return ex_lds_load(p);
+#endif
+        return *p;
+    }
+    POA_HD uint32_t rld(const uint32_t* p) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((AS & EX_AS_RING_LDS) != 0) return ex_lds_load(p);
+#endif
+        return *p;
+    }
+    POA_HD void rst(uint32_t* p, uint32_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((AS & EX_AS_RING_LDS) != 0) { ex_lds_store(p, v); return; }
+#endif
+        *p = v;
+    }
     const ExactGraph& G;
     ExactWork& W;
     const uint8_t* seq;
@@ -97,7 +144,7 @@ public:
     uint32_t layer_min = 0, n_layers = 0, pool_top = 0;
     uint32_t num_queued = 0, num_visited = 0, num_pruned = 0;
 
-    POA_HD ExactSearch(const ExactGraph& g, ExactWork& w, const uint8_t* s, uint32_t len, ExactCosts c)
+    POA_HD ExactSearchT(const ExactGraph& g, ExactWork& w, const uint8_t* s, uint32_t len, ExactCosts c)
         : G(g), W(w), seq(s), L(len), C(c) {}
 
     // ---- Score arithmetic (scoring/mod.rs:93-152) -------------------------------------------
@@ -113,7 +160,7 @@ public:
         return (st == EX_ST_M ? C.o : 0u) + length * C.e;
     }
     POA_HD bool is_symbol_equal(uint32_t row, uint8_t c) const {  // graphs/poa.rs:463-465
-        return row == G.end_row || G.sym[row] == c;
+        return row == G.end_row || gld(&G.sym[row]) == c;
     }
 
     // ---- visited table (gap_affine.rs:483-548) -----------------------------------------------
@@ -135,7 +182,7 @@ public:
     // ---- reached sets: BTreeSet<offset> per exit node as a two-level bitset (gap_affine.rs:711,:767-773) ---
     POA_HD void mark_reached(uint32_t row, uint32_t off, uint32_t st) {
         if (st != EX_ST_M) return;
-        const uint32_t x = G.exit_idx[row];
+        const uint32_t x = gld(&G.exit_idx[row]);
         if (x == EX_NIL) return;
         const uint32_t wi = off >> 6;
         if (wi >= W.wpn) { err = EX_POOL_FULL; return; }
@@ -145,14 +192,14 @@ public:
         if (old == 0) W.rsum[(uint64_t)x * W.swpn + (wi >> 6)] |= 1ull << (wi & 63);
     }
     POA_HD bool reached_any(uint32_t row) const {  // !reached_offsets.is_empty()
-        const uint64_t* s = W.rsum + (uint64_t)G.exit_idx[row] * W.swpn;
+        const uint64_t* s = W.rsum + (uint64_t)gld(&G.exit_idx[row]) * W.swpn;
         for (uint32_t i = 0; i < W.swpn; ++i) if (s[i]) return true;
         return false;
     }
     // largest reached offset < t, or EX_NIL  (row must be an exit row)
     POA_HD uint32_t reached_before(uint32_t row, uint32_t t) const {
         if (t == 0) return EX_NIL;
-        const uint32_t x = G.exit_idx[row];
+        const uint32_t x = gld(&G.exit_idx[row]);
         const uint64_t* b = W.reached + (uint64_t)x * W.wpn;
         const uint64_t* s = W.rsum + (uint64_t)x * W.swpn;
         uint32_t last = t - 1;
@@ -178,7 +225,7 @@ public:
     POA_HD uint32_t reached_from(uint32_t row, uint32_t t) const {
         const uint32_t wi = t >> 6;
         if (wi >= W.wpn) return EX_NIL;
-        const uint32_t x = G.exit_idx[row];
+        const uint32_t x = gld(&G.exit_idx[row]);
         const uint64_t* b = W.reached + (uint64_t)x * W.wpn;
         const uint64_t* s = W.rsum + (uint64_t)x * W.swpn;
         const uint64_t w = b[wi] & (~0ull << (t & 63));
@@ -214,8 +261,8 @@ public:
     // ---- heuristic (heuristic.rs:70-102 / :41-46) --------------------------------------------
     POA_HD uint32_t h(uint32_t row, uint32_t off, uint32_t st) const {
         if (C.heuristic == EX_H_DIJKSTRA) return 0;
-        uint32_t mn = G.dist_min[row]; mn = mn ? mn - 1 : 0;
-        uint32_t mx = G.dist_max[row]; mx = mx ? mx - 1 : 0;
+        uint32_t mn = gld(&G.dist_min[row]); mn = mn ? mn - 1 : 0;
+        uint32_t mx = gld(&G.dist_max[row]); mx = mx ? mx - 1 : 0;
         const uint32_t tmin = off + mn, tmax = off + mx;
         uint32_t gap;
         if (tmin > L) { gap = tmin - L; if (st != EX_ST_D) st = EX_ST_M; }
@@ -255,7 +302,7 @@ public:
         if (!reached_any(ex)) return true;
         if (row == ex) return true;
         const uint32_t tmin = off + b.min_dist, tmax = off + b.max_dist;
-        uint32_t mde = G.dist_min[ex]; mde = mde ? mde - 1 : 0;
+        uint32_t mde = gld(&G.dist_min[ex]); mde = mde ? mde - 1 : 0;
         if (tmax > L) return true;
         uint32_t prev = reached_before(ex, tmin);
         bool have_last = false;
@@ -294,17 +341,78 @@ public:
     }
 
     POA_HD bool prune(uint32_t score, uint32_t row, uint32_t off, uint32_t st) {
-        const uint32_t b0 = G.nbm_off[row], b1 = G.nbm_off[row + 1];
+        const uint32_t b0 = gld(&G.nbm_off[row]), b1 = gld(&G.nbm_off[row + 1]);
         if (b0 == b1) return false;
         for (uint32_t k = b0; k < b1; ++k)
-            if (!can_improve_bubble(G.nbm[k], row, off, st, score)) return true;
+            if (!can_improve_bubble(gld(&G.nbm[k]), row, off, st, score)) return true;
         return false;
     }
 
     // ---- bucket queue (queue.rs:31-70; gap_affine.rs:945-966) ----------------------------------
+    // bucket-queue state (wave search).  A descriptor word is top << 6 | n_top; BQ_EMPTY = no chunk.  A stack that runs empty
+    // keeps its last chunk (n_top == 0) until the search moves past its priority: the stacks of the current priority are
+    // refilled all the time (a state pushed into the bucket being drained), and would otherwise take a new chunk each time.
+    // Freed chunks go on a free list threaded through slot 0.
+    uint32_t bq_live = 0, bq_chunk_top = 0, bq_hi = 0, bq_free = EX_NIL;
+    bool bq_wr = true;  // wave kernel: in the sections every lane executes alike, only one lane stores
+    POA_HD uint32_t bq_alloc() {
+        if (bq_free != EX_NIL) { const uint32_t c = bq_free; bq_free = W.bq_chunks[(uint64_t)BQ_CHUNK * c].x; return c; }
+        if (bq_chunk_top >= W.bq_chunk_cap || bq_chunk_top >= (1u << 26)) { err = EX_POOL_FULL; return EX_NIL; }
+        return bq_chunk_top++;
+    }
+    POA_HD void bq_release(uint32_t c) {
+        if (bq_wr) W.bq_chunks[(uint64_t)BQ_CHUNK * c].x = bq_free;
+        bq_free = c;
+    }
+    POA_HD void bq_push(uint32_t prio, uint32_t st, uint32_t score, uint32_t row, uint32_t off) {
+        if (bq_live == 0) { layer_min = prio; bq_hi = prio; }  // queue.rs:32-35 (chunks kept by drained stacks are reused in place)
+        else {
+            const uint32_t lo = prio < layer_min ? prio : layer_min, hi = prio > bq_hi ? prio : bq_hi;
+            if (hi - lo >= W.bq_win) { err = EX_POOL_FULL; return; }
+            layer_min = lo; bq_hi = hi;
+        }
+        uint32_t* d = &W.bq_desc[3 * (prio & (W.bq_win - 1)) + st];
+        const uint32_t dw = rld(d);
+        uint32_t top = dw == BQ_EMPTY ? EX_NIL : dw >> 6, n = dw == BQ_EMPTY ? 0u : dw & 63u;
+        if (top == EX_NIL || n == BQ_CHUNK - 1) {
+            const uint32_t c = bq_alloc();
+            if (c == EX_NIL) return;
+            W.bq_chunks[(uint64_t)BQ_CHUNK * c] = ExU4{top, 0, 0, 0};
+            top = c; n = 0;
+        }
+        n += 1;
+        W.bq_chunks[(uint64_t)BQ_CHUNK * top + n] = ExU4{score, row, off, 0};
+        rst(d, top << 6 | n);
+        bq_live += 1;
+    }
+    // the stack the next pop comes from: lowest live priority, Match before Deletion before Insertion
+    POA_HD bool bq_current(uint32_t& st, BqDesc& d) {
+        if (bq_live == 0) return false;
+        for (;;) {
+            uint32_t* b = &W.bq_desc[3 * (layer_min & (W.bq_win - 1))];
+            const uint32_t d0 = rld(b), d1 = rld(b + 1), d2 = rld(b + 2);
+            if (d0 != BQ_EMPTY && (d0 & 63u)) { st = 0; d = BqDesc{d0 >> 6, d0 & 63u}; return true; }
+            if (d1 != BQ_EMPTY && (d1 & 63u)) { st = 1; d = BqDesc{d1 >> 6, d1 & 63u}; return true; }
+            if (d2 != BQ_EMPTY && (d2 & 63u)) { st = 2; d = BqDesc{d2 >> 6, d2 & 63u}; return true; }
+            // nothing left at this priority: its (empty) chunks go back, the ring slot is free for priority + bq_win
+            if (d0 != BQ_EMPTY) { bq_release(d0 >> 6); if (bq_wr) rst(b, BQ_EMPTY); }
+            if (d1 != BQ_EMPTY) { bq_release(d1 >> 6); if (bq_wr) rst(b + 1, BQ_EMPTY); }
+            if (d2 != BQ_EMPTY) { bq_release(d2 >> 6); if (bq_wr) rst(b + 2, BQ_EMPTY); }
+            layer_min += 1;
+        }
+    }
+    // remove the `pops` top entries of the current stack (pops <= d.n_top); `prev` = slot 0 of its top chunk
+    POA_HD void bq_drop(uint32_t st, BqDesc d, uint32_t pops, uint32_t prev) {
+        d.n_top -= pops;
+        if (d.n_top == 0 && prev != EX_NIL) { bq_release(d.top); d.top = prev; d.n_top = BQ_CHUNK - 1; }
+        if (bq_wr) rst(&W.bq_desc[3 * (layer_min & (W.bq_win - 1)) + st], d.top << 6 | d.n_top);
+        bq_live -= pops;
+    }
+
     POA_HD void queue_state(uint32_t row, uint32_t off, uint32_t st, uint32_t new_score) {
         const uint32_t pr64 = new_score + h(row, off, st);
         num_queued += 1;
+        if (W.bq_desc) { bq_push(pr64, st, new_score, row, off); return; }
         if (pr64 >= W.n_prio || pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; }
         const uint32_t prio = pr64;
         if (n_layers == 0) { n_layers = 1; layer_min = prio; }
@@ -381,10 +489,10 @@ public:
             if (err) return;
             if (off < L && update_if_lower(row, off + 1, EX_ST_I, ns)) queue_state(row, off + 1, EX_ST_I, ns);
         } else {
-            for (uint32_t e = G.succ_off[row]; e < G.succ_off[row + 1]; ++e) {
+            for (uint32_t e = gld(&G.succ_off[row]); e < gld(&G.succ_off[row + 1]); ++e) {
                 const uint32_t ns = score_add(score, C.e);
                 if (err) return;
-                if (update_if_lower(G.succ[e], off, EX_ST_D, ns)) queue_state(G.succ[e], off, EX_ST_D, ns);
+                if (update_if_lower(gld(&G.succ[e]), off, EX_ST_D, ns)) queue_state(gld(&G.succ[e]), off, EX_ST_D, ns);
             }
         }
     }
@@ -400,7 +508,7 @@ public:
             const ExStackEntry init = W.stack[0];
             if (init.offset == 0 && is_symbol_equal(init.row, seq[0])) {
                 if (update_if_lower(init.row, 1, EX_ST_M, dfa_score)) {
-                    W.stack[0] = ExStackEntry{init.row, 1, G.succ_off[init.row]};
+                    W.stack[0] = ExStackEntry{init.row, 1, gld(&G.succ_off[init.row])};
                     mark_reached(init.row, 1, EX_ST_M);
                     dfa_visited += 1;
                     if (1 == L) return Event{EV_REF_GRAPH_END, init.row, 0, init.row, 1};
@@ -409,10 +517,10 @@ public:
         }
         while (sp != 0) {
             ExStackEntry& parent = W.stack[sp - 1];
-            const uint32_t cend = G.succ_off[parent.row + 1];
+            const uint32_t cend = gld(&G.succ_off[parent.row + 1]);
             bool again = false;
             while (parent.it < cend) {
-                const uint32_t child = G.succ[parent.it++];
+                const uint32_t child = gld(&G.succ[parent.it++]);
                 if (child == G.end_row) {
                     update_if_lower(child, parent.offset, EX_ST_M, dfa_score);
                     return Event{EV_REF_GRAPH_END, parent.row, parent.offset, child, parent.offset};
@@ -426,7 +534,7 @@ public:
                         mark_reached(child, coff, EX_ST_M);
                         dfa_visited += 1;
                         if (sp >= W.stack_cap) { err = EX_POOL_FULL; return Event{EV_NONE, 0, 0, 0, 0}; }
-                        W.stack[sp++] = ExStackEntry{child, coff, G.succ_off[child]};
+                        W.stack[sp++] = ExStackEntry{child, coff, gld(&G.succ_off[child])};
                         again = true;
                         break;
                     }
@@ -441,9 +549,203 @@ public:
     }
     uint32_t num_pruned_dfa = 0;  // DFA-internal count (dfa.rs:103); NOT added to AstarResult::num_pruned
 
-    // ---- main loop (astar.rs:124-226) -----------------------------------------------------------
-    POA_HD ExactResult run() {
-        ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+
+    // ---- one-round-trip path for the common shape of a popped state ----------------------------------
+    // A node with a single successor whose bubbles (other than the one it exits itself) all lie one fixed distance ahead —
+    // every node of a chain, every allele of a SNP bubble — needs, to be tested and expanded, a fixed set of cells: its own,
+    // the three (two) cells it may relax, the query symbol, and of the exit row the reached bits around the target offset
+    // t with the Match scores next to t.  inspect_fast issues ALL those loads before the first use, so that the whole test
+    // costs one memory round trip (the generic code chases pointer after pointer: word of the set, then the cell it names,
+    // then the next word ...).  Whatever does not fit the shape — several successors, a greedy match to extend, the
+    // end row, a bubble with paths of different lengths, far-away reached offsets, ends-free spans — takes the generic code:
+    // same results, more round trips.  The logic below is reached.rs:38-255 specialised to tmin == tmax.
+    uint32_t n_fast = 0;      // states tested on this path (statistics)
+    struct FastItem {
+        uint32_t kind;        // 0: generic path; 1: fast path applies
+        uint32_t c;           // the single successor row
+        uint32_t own;         // table value of the popped state
+        uint32_t t0, t1, t2;  // M: M[c][j+1], I[v][j+1], D[c][j];  I: M[v][j], I[v][j+1];  D: M[v][j], D[c][j]
+    };
+    POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
+        F.kind = 0;
+        const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
+        const uint32_t b0 = gld(&G.nbm_off[v]), b1 = gld(&G.nbm_off[v + 1]);
+        bool fits = !C.ends_free && s1 - s0 == 1 && v != G.end_row && W.swpn == 1 && j + 2 < W.pitch && g < 0xFFFF0000u;
+        uint32_t c = 0, ex = EX_NIL, dist = 0;
+        if (fits) {
+            c = gld(&G.succ[s0]);
+            for (uint32_t k = b0; k < b1; ++k) {
+                const FlatGraph::NodeBubble b = gld(&G.nbm[k]);
+                if (b.exit_row == v) continue;
+                if (ex != EX_NIL || b.min_dist != b.max_dist) { fits = false; break; }
+                ex = b.exit_row; dist = b.min_dist;
+            }
+        }
+        uint8_t qj = 0;
+        if (fits && st == EX_ST_M) {
+            // a Match state goes through the greedy extension: only "first successor mismatches" is handled here
+            if (c == G.end_row || j >= L) fits = false;
+            else {
+                qj = seq[j];
+                if (gld(&G.sym[c]) == qj) fits = false;
+                if (j == 0 && L != 0 && is_symbol_equal(v, seq[0])) fits = false;  // the offset-0 special case, dfa.rs:146-167
+            }
+        }
+        if (fits) {
+        // ---- every load of the step, before any use ----
+        const uint32_t own = *cell(v, j, st);
+        uint32_t t0, t1, t2 = EX_INF;
+        if (st == EX_ST_M) { t0 = *cell(c, j + 1, EX_ST_M); t1 = *cell(v, j + 1, EX_ST_I); t2 = *cell(c, j, EX_ST_D); }
+        else if (st == EX_ST_I) { t0 = *cell(v, j, EX_ST_M); t1 = j < L ? *cell(v, j + 1, EX_ST_I) : EX_INF; }
+        else { t0 = *cell(v, j, EX_ST_M); t1 = *cell(c, j, EX_ST_D); }
+        const bool probe = C.prune && ex != EX_NIL && j + dist <= L;
+        const uint32_t t = j + dist;
+        uint64_t w0 = 0, w1 = 0, w2 = 0, sum = 0;
+        uint32_t ta = EX_INF, tb = EX_INF, tc = EX_INF;
+        uint32_t wi = 0;
+        if (probe) {
+            const uint32_t x = gld(&G.exit_idx[ex]);
+            const uint64_t* bits = W.reached + (uint64_t)x * W.wpn;
+            wi = t >> 6;
+            sum = W.rsum[(uint64_t)x * W.swpn];
+            w1 = bits[wi];
+            if (wi) w0 = bits[wi - 1];
+            if (wi + 1 < W.wpn) w2 = bits[wi + 1];
+            if (t) ta = *cell(ex, t - 1, EX_ST_M);
+            tb = *cell(ex, t, EX_ST_M);
+            tc = *cell(ex, t + 1, EX_ST_M);
+        }
+        F.kind = 1; F.c = c; F.own = own; F.t0 = t0; F.t1 = t1; F.t2 = t2;
+        n_fast += 1;
+
+        if (g > own) return 1;                      // stale (astar.rs:146)
+        if (!probe || sum == 0) return 0;           // no bubble to test / nothing reached at the exit yet (reached.rs:52-54)
+        // nearest reached offsets around t: prev < t, t itself, nxt > t
+        uint32_t prev = EX_NIL, nxt = EX_NIL;
+        const bool at_t = (w1 >> (t & 63)) & 1;
+        {
+            const uint64_t lo = (t & 63) ? (w1 & (~0ull >> (64 - (t & 63)))) : 0ull;
+            if (lo) prev = wi * 64 + 63 - (uint32_t)clz64(lo);
+            else if (wi && w0) prev = (wi - 1) * 64 + 63 - (uint32_t)clz64(w0);
+            else if (wi > 1 && (sum & (~0ull >> (64 - (wi - 1))))) prev = reached_before(ex, (wi - 1) * 64);   // far: generic lookup
+            const uint64_t hi = (t & 63) != 63 ? (w1 & (~0ull << ((t & 63) + 1))) : 0ull;
+            if (hi) nxt = wi * 64 + (uint32_t)ctz64(hi);
+            else if (wi + 1 < W.wpn && w2) nxt = (wi + 1) * 64 + (uint32_t)ctz64(w2);
+            else if (wi + 2 < W.wpn && (sum >> (wi + 2))) nxt = reached_from(ex, (wi + 2) * 64);
+        }
+        auto score_at = [&](uint32_t o2) -> uint32_t {
+            if (o2 == t) return tb;
+            if (o2 + 1 == t) return ta;
+            if (o2 == t + 1) return tc;
+            return get_score(ex, o2, EX_ST_M);
+        };
+        uint32_t mde = gld(&G.dist_min[ex]); mde = mde ? mde - 1 : 0;
+        const uint32_t ls = prev != EX_NIL ? score_at(prev) : 0, rs = nxt != EX_NIL ? score_at(nxt) : 0;
+        // a reached cell holds a score; if it does not the generic code reports what the reference would (a panic)
+        bool improve;
+        if ((prev != EX_NIL && ls == EX_INF) || (nxt != EX_NIL && rs == EX_INF) || (at_t && tb == EX_INF)) { F.kind = 0; fits = false; improve = true; }
+        else
+        if (at_t) {
+            // the loop body of reached.rs:67-141 runs once with next == t; afterwards prev == t (reached.rs:139, :177-186)
+            improve = (st == EX_ST_D && tb + C.o > g) || (prev != EX_NIL && st == EX_ST_I && ls + C.o > g);
+            if (!improve) {
+                const uint32_t implicit = prev != EX_NIL ? (ls + gap_cost(EX_ST_M, t - prev) < tb ? ls + gap_cost(EX_ST_M, t - prev) : tb) : tb;
+                improve = g < implicit;
+            }
+            if (!improve && st == EX_ST_I) improve = tb + C.o > g;
+        } else {
+            // reached.rs:143-186 with an empty range: one test at t between prev and nxt
+            if (prev != EX_NIL && nxt != EX_NIL) {
+                const uint32_t fl = ls + gap_cost(EX_ST_M, t - prev), fr = rs + gap_cost(EX_ST_M, nxt - t);
+                improve = g < ((nxt - t > mde) ? fl : (fl < fr ? fl : fr));
+            } else if (nxt != EX_NIL) {
+                improve = (nxt - t > mde) ? true : g < rs + gap_cost(EX_ST_M, nxt - t);
+            } else if (prev != EX_NIL) {
+                improve = g < ls + gap_cost(EX_ST_M, t - prev);
+            } else improve = true;
+            if (!improve && prev != EX_NIL && st == EX_ST_I) improve = ls + C.o > g;
+        }
+        if (fits) return improve ? 0 : 2;
+        }
+        return inspect_skip(g, v, j, st);
+    }
+    // the expansion of a state inspect_fast let through (F.kind == 1); true when the search ends (never on this path)
+    POA_HD void mark_reached_atomic(uint32_t row, uint32_t off) {
+        const uint32_t x = gld(&G.exit_idx[row]);
+        if (x == EX_NIL) return;
+        const uint32_t wi = off >> 6;
+        if (wi >= W.wpn) { err = EX_POOL_FULL; return; }
+        uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
+        uint64_t* sm = W.rsum + (uint64_t)x * W.swpn + (wi >> 6);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // nobody waits for these: the next reader is this wave, behind them in its own memory stream
+        __hip_atomic_fetch_or(w, 1ull << (off & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_or(sm, 1ull << (wi & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+        *w |= 1ull << (off & 63);
+        *sm |= 1ull << (wi & 63);
+#endif
+    }
+    POA_HD void process_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, const FastItem& F) {
+        if (st == EX_ST_M) mark_reached_atomic(v, j);
+        num_visited += 1;
+        if (err) return;
+        const uint32_t c = F.c;
+        if (st == EX_ST_M) {
+            // greedy extension: the only successor mismatches -> expand_mismatch (gap_affine.rs:393-430), then nothing is left
+            const uint32_t nm = g + C.x, ng = g + C.o + C.e;
+            if (nm < F.t0) { *cell(c, j + 1, EX_ST_M) = nm; queue_state(c, j + 1, EX_ST_M, nm); }
+            if (ng < F.t1) { *cell(v, j + 1, EX_ST_I) = ng; queue_state(v, j + 1, EX_ST_I, ng); }
+            if (ng < F.t2) { *cell(c, j, EX_ST_D) = ng; queue_state(c, j, EX_ST_D, ng); }
+        } else if (st == EX_ST_I) {
+            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
+            const uint32_t ns = g + C.e;
+            if (j < L && ns < F.t1) { *cell(v, j + 1, EX_ST_I) = ns; queue_state(v, j + 1, EX_ST_I, ns); }
+        } else {
+            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
+            const uint32_t ns = g + C.e;
+            if (ns < F.t1) { *cell(c, j, EX_ST_D) = ns; queue_state(c, j, EX_ST_D, ns); }
+        }
+    }
+
+    // ---- one popped state (astar.rs:141-216) ------------------------------------------------------
+    // 0: goes on to process_popped; 1: stale entry (astar.rs:146); 2: pruned (astar.rs:155-158).  Reads only.
+    POA_HD uint32_t inspect_skip(uint32_t score, uint32_t row, uint32_t off, uint32_t st) {
+        if (score > get_score(row, off, st)) return 1;
+        if (is_end(row, off, st)) return 0;
+        if (C.prune && prune(score, row, off, st)) return 2;
+        return 0;
+    }
+    // everything after the stale / prune tests; true when the search ends here (R.end_* set)
+    POA_HD bool process_popped(uint32_t score, uint32_t row, uint32_t off, uint32_t st, ExactResult& R, uint32_t& end_score) {
+        if (is_end(row, off, st)) { num_visited += 1; end_score = score; R.end_row = row; R.end_off = off; return true; }
+        if (err) return false;
+        mark_reached(row, off, st);
+        num_visited += 1;
+        if (st == EX_ST_M) {
+            sp = 0; dfa_visited = 0; dfa_score = score;
+            W.stack[sp++] = ExStackEntry{row, off, gld(&G.succ_off[row])};
+            for (;;) {
+                const Event ev = dfa_extend();
+                if (err || ev.kind == EV_NONE) break;
+                if (ev.kind == EV_REF_GRAPH_END) {
+                    if (is_end(ev.crow, ev.coff, EX_ST_M)) { end_score = score; R.end_row = ev.crow; R.end_off = ev.coff; return true; }
+                    expand_ref_graph_end(ev.prow, ev.poff, score);
+                } else if (ev.kind == EV_QUERY_END) {
+                    expand_query_end(ev.poff, ev.crow, score);
+                } else {
+                    expand_mismatch(ev.prow, ev.poff, ev.crow, ev.coff, score);
+                }
+                if (err) break;
+            }
+            num_visited += dfa_visited;  // skipped by `break 'main` above (astar.rs:172,:205)
+        } else {
+            expand_all(score, row, off, st);
+        }
+        return false;
+    }
+    // the initial states (astar.rs:133-139)
+    POA_HD void push_initial_states() {
         if (C.ends_free && C.gfb_kind == EX_BOUND_UNBOUNDED && G.n_rows > 2) {
             // gap_affine.rs:150-163: every real node at offset 0, pushed in reverse node-index order
             for (uint32_t v = G.n_rows; v-- > 0;) {
@@ -456,37 +758,57 @@ public:
             queue_state(G.start_row, 0, EX_ST_M, 0);
             *cell(G.start_row, 0, EX_ST_M) = 0;  // visited_data.set_score
         }
+    }
+
+    // ---- main loop (astar.rs:124-226) -----------------------------------------------------------
+    POA_HD ExactResult run() {
+        ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+        push_initial_states();
         uint32_t end_score = EX_INF;
         bool found = false;
         while (!found && !err) {
             uint32_t score, row, off, st;
             if (!pop_state(score, row, off, st)) { err = EX_PANIC; break; }  // "Could not align sequence!"
-            if (score > get_score(row, off, st)) continue;
-            if (is_end(row, off, st)) { num_visited += 1; end_score = score; found = true; R.end_row = row; R.end_off = off; break; }
-            if (C.prune && prune(score, row, off, st)) { num_pruned += 1; continue; }
+            const uint32_t sk = inspect_skip(score, row, off, st);
+            if (sk == 2) num_pruned += 1;
+            if (sk || err) continue;
+            found = process_popped(score, row, off, st, R, end_score);
+        }
+        R.status = err ? err : (found ? EX_OK : EX_PANIC);
+        R.score = end_score;
+        R.num_queued = num_queued; R.num_visited = num_visited; R.num_pruned = num_pruned;
+        return R;
+    }
+
+    // The same search over the bucket queue, in the step structure of the wave kernel (poa_wsearch.hpp), one lane at a time:
+    // a step looks at the top `batch` entries of the current stack; the leading entries that are stale or pruned change
+    // nothing (inspect_skip only reads), so they are all popped together with the first entry that is neither, which is
+    // then processed.  Order of every write and of every push is the reference's.  (Host build: the executable
+    // specification of the kernel's schedule; tests/test_exact_replay.py diffs it against the oracle.)
+    POA_HD ExactResult run_buckets(uint32_t batch, bool use_fast = true) {
+        ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+        push_initial_states();
+        uint32_t end_score = EX_INF;
+        bool found = false;
+        while (!found && !err) {
+            uint32_t st; BqDesc d;
+            if (!bq_current(st, d)) { err = EX_PANIC; break; }
+            const uint32_t nb = d.n_top < batch ? d.n_top : batch;
+            const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
+            uint32_t n = nb;
+            ExU4 e{0, 0, 0, 0};
+            FastItem F{0, 0, 0, 0, 0, 0};
+            for (uint32_t i = 0; i < nb && !err; ++i) {
+                e = ch[d.n_top - i];
+                const uint32_t sk = use_fast ? inspect_fast(e.x, e.y, e.z, st, F) : inspect_skip(e.x, e.y, e.z, st);
+                if (sk == 0) { n = i; break; }
+                if (sk == 2) num_pruned += 1;
+            }
             if (err) break;
-            mark_reached(row, off, st);
-            num_visited += 1;
-            if (st == EX_ST_M) {
-                sp = 0; dfa_visited = 0; dfa_score = score;
-                W.stack[sp++] = ExStackEntry{row, off, G.succ_off[row]};
-                for (;;) {
-                    const Event ev = dfa_extend();
-                    if (err || ev.kind == EV_NONE) break;
-                    if (ev.kind == EV_REF_GRAPH_END) {
-                        if (is_end(ev.crow, ev.coff, EX_ST_M)) { end_score = score; found = true; R.end_row = ev.crow; R.end_off = ev.coff; break; }
-                        expand_ref_graph_end(ev.prow, ev.poff, score);
-                    } else if (ev.kind == EV_QUERY_END) {
-                        expand_query_end(ev.poff, ev.crow, score);
-                    } else {
-                        expand_mismatch(ev.prow, ev.poff, ev.crow, ev.coff, score);
-                    }
-                    if (err) break;
-                }
-                if (found) break;  // `break 'main` skips the dfa counter update (astar.rs:172,:205)
-                num_visited += dfa_visited;
-            } else {
-                expand_all(score, row, off, st);
+            bq_drop(st, d, n < nb ? n + 1 : nb, ch[0].x);
+            if (n < nb) {
+                if (F.kind) process_fast(e.x, e.y, e.z, st, F);
+                else found = process_popped(e.x, e.y, e.z, st, R, end_score);
             }
         }
         R.status = err ? err : (found ? EX_OK : EX_PANIC);
@@ -495,5 +817,6 @@ public:
         return R;
     }
 };
+using ExactSearch = ExactSearchT<0>;
 
 }  // namespace poa_amd

@@ -1,0 +1,167 @@
+// Wave-per-query replay of the reference's search (exact / hybrid mode).
+//
+// The reference's tie-breaks are decided by the order in which its best-first search pops states (bucket queue, three LIFO
+// stacks per bucket, pruning against the bubble exits reached so far), so an exact replay has to keep that order.  What it
+// does not have to keep is one memory round trip after another per pop.  Here a wavefront owns a query and a step is:
+//
+//   1. the wave finds the stack the next pop comes from (descriptor ring in LDS) and reads its top entries, one per lane
+//      (the entries of a stack are contiguous in 64-slot chunks: one coalesced load);
+//   2. every lane tests ITS entry as if it were popped now: stale (a lower score is on the table, astar.rs:146) or pruned
+//      (reached.rs:38-189) — reads only, all lanes' loads in flight together;
+//   3. the leading run of stale / pruned entries changes nothing, so the whole run is popped at once together with the
+//      first entry that survives; that one is expanded by its own lane (greedy extension, relaxations, pushes) while the
+//      table and the queue are exactly what the reference's would be at that pop.
+//
+// ExactSearch::run_buckets (poa_exact.hpp) is the same schedule one lane at a time; compiled for the host it is diffed
+// against the oracle (tests/test_exact_replay.py), and this kernel is diffed against both on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "poa_exact_kernel.hpp"
+
+namespace poa_amd {
+
+struct WSearchParams {
+    ExactParams E;            // graph, queries, planes, reached sets, DFA stacks, costs, status / end cell
+    ExU4* chunks;             // per slot: chunk_cap chunks of BQ_CHUNK slots
+    uint32_t chunk_cap;
+    uint32_t win;             // descriptor ring: priorities per wave (power of two)
+    uint32_t* ring_global;    // null: the rings live in LDS; else [slots * 3 * win] in global memory
+    uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
+    uint32_t waves_per_block;
+    uint32_t* counters;       // optional [4 * total]: num_queued, num_visited, num_pruned, steps (null: not kept)
+};
+
+__device__ __forceinline__ uint32_t ws_bcast(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t ws_wave_sum(uint32_t v) {
+    for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
+template <int AS>
+__device__ __forceinline__ void ws_search_query(const WSearchParams& P, const ExactGraph& G, uint32_t* ring, uint32_t lane, uint32_t wave);
+
+__global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const ExactParams& E = P.E;
+    ExactGraph G = E.G;
+    const uint32_t nthreads = blockDim.x;
+    if (P.graph_lds) {
+        uint32_t at = 0;
+        auto stage = [&](const void* src, uint64_t bytes) {
+            uint8_t* dst = lds + at;
+            const uint32_t words = (uint32_t)((bytes + 3) / 4);
+            const uint32_t* s32 = static_cast<const uint32_t*>(src);
+            for (uint32_t i = threadIdx.x; i < words; i += nthreads) reinterpret_cast<uint32_t*>(dst)[i] = s32[i];
+            at += (uint32_t)((bytes + 15) & ~15ull);
+            return dst;
+        };
+        const uint32_t n = E.G.n_rows;
+        G.sym = stage(E.G.sym, n);
+        G.succ_off = reinterpret_cast<const uint32_t*>(stage(E.G.succ_off, 4ull * (n + 1)));
+        G.nbm_off = reinterpret_cast<const uint32_t*>(stage(E.G.nbm_off, 4ull * (n + 1)));
+        G.succ = reinterpret_cast<const uint32_t*>(stage(E.G.succ, 4ull * E.n_succ));
+        G.dist_min = reinterpret_cast<const uint32_t*>(stage(E.G.dist_min, 4ull * n));
+        G.dist_max = reinterpret_cast<const uint32_t*>(stage(E.G.dist_max, 4ull * n));
+        G.exit_idx = reinterpret_cast<const uint32_t*>(stage(E.G.exit_idx, 4ull * n));
+        G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(E.G.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)E.n_nbm));
+    }
+    // (the wave index is uniform: say so, and every per-query pointer below lives in scalar registers)
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // descriptor ring of this wave: LDS, or (a priority range too wide for it) the slot's slice of P.ring_global
+    uint32_t* ring = P.ring_global ? nullptr : reinterpret_cast<uint32_t*>(lds + P.graph_lds) + (uint64_t)wave * 3 * P.win;
+    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;
+    if (P.ring_global && slot < P.E.n_queries) ring = P.ring_global + (uint64_t)slot * 3 * P.win;
+    if (ring) for (uint32_t i = lane; i < 3 * P.win; i += 64) ring[i] = BQ_EMPTY;
+    __syncthreads();
+    if (slot >= P.E.n_queries) return;
+    // graph arrays and descriptor ring both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers
+    if (P.graph_lds && !P.ring_global) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS>(P, G, ring, lane, wave);
+    else ws_search_query<0>(P, G, ring, lane, wave);
+}
+
+template <int AS>
+__device__ __forceinline__ void ws_search_query(const WSearchParams& P, const ExactGraph& G, uint32_t* ring, uint32_t lane, uint32_t wave) {
+    const ExactParams& E = P.E;
+    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;
+    const uint32_t qi = E.first_query + slot;
+    if (E.hybrid && E.dense_flags[qi] == 0) return;
+    const uint64_t qbeg = E.qoff[qi];
+    const uint32_t L = (uint32_t)(E.qoff[qi + 1] - qbeg);
+    ExactWork W;
+    W.T = E.planes + E.plane_off[qi];
+    W.n_rows = E.G.n_rows;
+    W.pitch = E.pitch[qi];
+    W.reached = E.reached + (uint64_t)slot * E.G.n_exit * E.wpn;
+    W.rsum = E.rsum + (uint64_t)slot * E.G.n_exit * E.swpn;
+    W.wpn = E.wpn; W.swpn = E.swpn;
+    W.head = nullptr; W.n_prio = 0xFFFFFFFFu;
+    W.pool = nullptr; W.pool_cap = 0;
+    W.stack = E.stack + (uint64_t)slot * E.stack_cap;
+    W.stack_cap = E.stack_cap;
+    W.bq_desc = ring; W.bq_win = P.win;
+    W.bq_chunks = P.chunks + (uint64_t)slot * P.chunk_cap * BQ_CHUNK;
+    W.bq_chunk_cap = P.chunk_cap;
+
+    ExactSearchT<AS> S(G, W, E.qseq + qbeg, L, E.C);
+    ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+    uint32_t end_score = EX_INF, found = 0, steps = 0;
+
+    // uniform state lives identically in every lane; whatever one lane changes alone is broadcast afterwards
+    auto adopt = [&](uint32_t from) {
+        S.err = ws_bcast(S.err, from);
+        S.layer_min = ws_bcast(S.layer_min, from);
+        S.bq_live = ws_bcast(S.bq_live, from);
+        S.bq_hi = ws_bcast(S.bq_hi, from);
+        S.bq_chunk_top = ws_bcast(S.bq_chunk_top, from);
+        S.bq_free = ws_bcast(S.bq_free, from);
+        found = ws_bcast(found, from);
+        end_score = ws_bcast(end_score, from);
+        R.end_row = ws_bcast(R.end_row, from);
+        R.end_off = ws_bcast(R.end_off, from);
+    };
+    if (lane == 0) S.push_initial_states();
+    adopt(0);
+    S.bq_wr = lane == 0;
+
+    while (!found && !S.err) {
+        uint32_t st; BqDesc d;
+        if (!S.bq_current(st, d)) { S.err = EX_PANIC; break; }  // "Could not align sequence!" (astar.rs:142-144)
+        const uint32_t nb = d.n_top;  // <= 63 entries in the top chunk: lane i takes the i-th from the top
+        const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
+        const bool act = lane < nb;
+        const ExU4 e = ch[act ? d.n_top - lane : 0];  // the idle lanes read slot 0: {previous chunk}
+        uint32_t sk = 1;
+        typename ExactSearchT<AS>::FastItem F{0, 0, 0, 0, 0, 0};
+        if (act) sk = S.inspect_fast(e.x, e.y, e.z, st, F);
+        // first entry that is neither stale nor pruned (a lane whose test hit an error stops the run as well)
+        const uint64_t stop = __ballot(act && (sk == 0 || S.err != 0));
+        const uint32_t n = stop ? (uint32_t)__builtin_ctzll(stop) : nb;
+        if (lane < n && sk == 2) S.num_pruned += 1;   // per-lane tallies, summed at the end
+        if (lane > n) S.err = 0;                      // tests beyond the run are discarded with whatever they hit
+        const uint32_t prev = ws_bcast(e.x, 63);      // lane 63 is never active (nb <= 63)
+        S.bq_drop(st, d, n < nb ? n + 1 : nb, prev);
+        steps += 1;
+        if (n < nb) {
+            if (lane == n && !S.err) {
+                S.bq_wr = true;
+                if (F.kind) S.process_fast(e.x, e.y, e.z, st, F);
+                else found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+                S.bq_wr = lane == 0;
+            }
+            adopt(n);
+        }
+    }
+
+    const uint32_t nq = ws_wave_sum(S.num_queued), nv = ws_wave_sum(S.num_visited), np = ws_wave_sum(S.num_pruned);
+    if (lane == 0) {
+        E.status[qi] = S.err ? S.err : (found ? EX_OK : EX_PANIC);
+        E.end_cell[2 * qi] = R.end_row;
+        E.end_cell[2 * qi + 1] = R.end_off;
+        if (P.counters) {
+            P.counters[4 * qi] = nq; P.counters[4 * qi + 1] = nv; P.counters[4 * qi + 2] = np; P.counters[4 * qi + 3] = steps;
+        }
+    }
+}
+
+}  // namespace poa_amd

@@ -11,20 +11,36 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--queries", type=int, default=2000)
 ap.add_argument("--mode", default="exact")
 ap.add_argument("--check", type=int, default=1)
+ap.add_argument("--reps", type=int, default=2)
 args = ap.parse_args()
 g, (qseq, qoff) = W.config2(n_queries=args.queries)
 costs = aligner.GapAffine(4, 2, 6)
 rb = aligner.ResidentBatch(g, qseq, qoff)
 cfg = aligner.make_config(args.mode, queue_entries_per_cell=0.25)
 rb.run(costs, None, cfg); rb.stats()
-t0 = time.time(); rb.run(costs, None, cfg); st = rb.stats(); dt = time.time() - t0
+best = None
+for _ in range(args.reps):
+    t0 = time.time(); rb.run(costs, None, cfg); st = rb.stats(); dt = time.time() - t0
+    if best is None or dt < best[0]:
+        best = (dt, st)
+dt, st = best
 res = rb.fetch()
-out = dict(mode=args.mode, queries=args.queries, wall_s=round(dt, 4), ms_forward=st["ms_forward"], ms_traceback=st["ms_traceback"],
-           ms_exact=st["ms_exact"], n_exact=res.stats["n_exact"], flagged=int((res.flags != 0).sum()),
-           overflow=int(((res.flags & 0x40) != 0).sum()), lanes=os.environ.get("POA_EXACT_LANES", "64"))
+cells = g.n * float((np.diff(qoff) + 1).sum())
+out = dict(mode=args.mode, queries=args.queries, wall_s=round(dt, 4), gcells_per_s=round(cells / dt / 1e9, 2), ms_forward=st["ms_forward"],
+           ms_traceback=st["ms_traceback"], ms_exact=st["ms_exact"], n_exact=res.stats["n_exact"], flagged=int((res.flags != 0).sum()),
+           overflow=int(((res.flags & 0x40) != 0).sum()), impl=os.environ.get("POA_EXACT_IMPL", "wave"))
+try:
+    sc = rb.search_counters()
+    sel = sc[:, 3] > 0
+    if sel.any():
+        out.update(pops_mean=float(sc[sel, 0].mean()), steps_mean=float(sc[sel, 3].mean()), steps_max=int(sc[sel, 3].max()),
+                   us_per_step_longest=round(st["ms_exact"] * 1e3 / float(sc[sel, 3].max()), 3))
+except Exception as ex:  # lane implementation keeps no counters
+    out.update(counters=str(ex)[:60])
 if args.check:
     og = O.OracleGraph.from_csr(g.as_dict())
-    A = og.astar_batch(qseq, qoff, O.Costs(4, 6, 2), O.H_MINGAP, True, threads=16)
-    same = sum(res.raw_alignment(i) == O.batch_alignment(A, i) for i in range(args.queries))
-    out.update(score_equal=int((res.score == A["score"]).sum()), alignment_identical=same)
+    n = min(args.queries, args.check if args.check > 1 else args.queries)
+    A = og.astar_batch(qseq[:int(qoff[n])], qoff[:n + 1], O.Costs(4, 6, 2), O.H_MINGAP, True, threads=16)
+    same = sum(res.raw_alignment(i) == O.batch_alignment(A, i) for i in range(n))
+    out.update(checked=n, score_equal=int((res.score[:n] == A["score"]).sum()), alignment_identical=same)
 print(json.dumps(out))

@@ -3,6 +3,8 @@
 // without a GPU.  Not shipped; built by tests/test_exact_replay.py.
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -12,7 +14,13 @@
 
 using namespace poa_amd;
 
+static uint32_t g_batch = 0, g_win = 0;
+
 extern "C" {
+
+// 0: linked-list queue (ExactSearch::run); n > 0: bucket queue stepped in batches of n (ExactSearch::run_buckets)
+void exact_host_set_batch(uint32_t n) { g_batch = n; }
+void exact_host_set_window(uint32_t w) { g_win = w; }  // 0: a window that always suffices
 
 // returns status (EX_*), or negative POA_ERR_* for graph errors.
 // planes (optional): M/I/D as [node][len+1]; out[0..3] = score, num_queued, num_visited, num_pruned
@@ -40,10 +48,23 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     std::vector<ExStackEntry> stack(n + len + 8);
     ExactWork W{T.data(), g.n, pitch, reached.data(), rsum.data(), wpn, swpn, head.data(), n_prio,
                 pool.data(), (uint32_t)pool.size(), stack.data(), (uint32_t)stack.size()};
+    // bucket queue of the wave search (batch > 0): a small ring so that the window logic is exercised
+    std::vector<uint32_t> bq_desc;
+    std::vector<ExU4> bq_chunks;
+    if (g_batch) {
+        uint32_t win = 64;
+        const uint32_t need = 2 * (std::max<uint32_t>(x, (uint32_t)o + e) + o + (uint32_t)(g.n + 2) * e) + 8;
+        while (win < need) win *= 2;
+        if (g_win) win = g_win;
+        bq_desc.assign((size_t)3 * win, BQ_EMPTY);
+        bq_chunks.resize((size_t)BQ_CHUNK * (pool.size() / 32 + 3 * win + 64));
+        W.bq_desc = bq_desc.data(); W.bq_win = win; W.bq_chunks = bq_chunks.data(); W.bq_chunk_cap = (uint32_t)(bq_chunks.size() / BQ_CHUNK);
+    }
     ExactCosts EC{x, o, e, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0};
     if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
     ExactSearch S(G, W, seq, len, EC);
-    ExactResult R = S.run();
+    ExactResult R = g_batch ? S.run_buckets(g_batch) : S.run();
+    if (getenv("EXH_VERBOSE")) fprintf(stderr, "chunks used %u of %u, status %u, fast-path tests %u, queued %u\n", S.bq_chunk_top, W.bq_chunk_cap, R.status, S.n_fast, R.num_queued);
     out[0] = R.score; out[1] = R.num_queued; out[2] = R.num_visited; out[3] = R.num_pruned;
     if (span) { out[4] = g.rows[R.end_row].node; out[5] = R.end_off; }
     if (pm) {

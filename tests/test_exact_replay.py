@@ -31,7 +31,17 @@ def harness():
     X = C.CDLL(out)
     X.exact_host_run.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [C.c_uint8] * 3 + [C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     X.exact_host_bubbles.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp] * 5 + [C.c_uint32]
+    X.exact_host_set_batch.argtypes = [C.c_uint32]
     return X
+
+
+@pytest.fixture(params=[0, 1, 7, 64], ids=["linked_list_queue", "buckets_batch1", "buckets_batch7", "buckets_batch64"])
+def queue_variant(request, harness):
+    """0: ExactSearch::run (linked-list queue, the one-search-per-lane kernel); n: ExactSearch::run_buckets(n), the
+    step schedule of the wave-per-query kernel (poa_wsearch.hpp) over the bucket queue."""
+    harness.exact_host_set_batch(request.param)
+    yield request.param
+    harness.exact_host_set_batch(0)
 
 
 def _oracle_table(oracle, og, q, costs, heur, prune, n):
@@ -96,7 +106,7 @@ def test_product_bubble_index_matches_oracle(oracle, harness):
             assert [tuple(x) for x in nbm[off[v]:off[v + 1]].tolist()] == bi["node_bubble_map"][v]
 
 
-def test_replay_equals_oracle_search_cpu(oracle, harness):
+def test_replay_equals_oracle_search_cpu(oracle, harness, queue_variant):
     n_ok = 0
     for seed in range(60):
         rng = np.random.Generator(np.random.PCG64(1000 + seed))
@@ -136,7 +146,7 @@ def _gpu_exact_vs_astar(engine, oracle, g, qs, costs=(4, 6, 2), cfg_cls="AffineM
     return n, res
 
 
-def test_replay_equals_oracle_search_ends_free_cpu(oracle, harness):
+def test_replay_equals_oracle_search_ends_free_cpu(oracle, harness, queue_variant):
     """AlignmentType::EndsFree: the replay's visited table, score and counters equal the oracle's for every kind of
     bound the reference distinguishes (gap_affine.rs:136-248)."""
     U, INC, EXC = oracle.UNBOUNDED, oracle.INCLUDED, oracle.EXCLUDED
@@ -267,7 +277,11 @@ def test_gpu_exact_overflow_keeps_dense_result(engine, oracle):
     al_d = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 2, 6)))
     al_x = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 2, 6)), mode="exact", queue_entries_per_cell=1e-6)
     d = al_d.align_batch(g, qseq=qseq, qoff=qoff)
-    x = al_x.align_batch(g, qseq=qseq, qoff=qoff)
+    os.environ["POA_WS_CHUNK_CAP"] = "6"   # wave search: every live stack holds a chunk, so the ring adds to the pool; cap it
+    try:
+        x = al_x.align_batch(g, qseq=qseq, qoff=qoff)
+    finally:
+        del os.environ["POA_WS_CHUNK_CAP"]
     for i in range(8):
         if int(x.flags[i]) & 0x40:  # POA_FLAG_EXACT_OVERFLOW: dense result kept
             assert int(x.score[i]) == int(d.score[i]) and x.raw_alignment(i) == d.raw_alignment(i)
