@@ -204,6 +204,7 @@ struct poa_batch {
     uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0, ex_swpn = 0;
     uint32_t ex_win = 64;              // wave search: priorities in the descriptor ring (power of two)
     uint32_t ex_skew = 0;              // max over nodes of dist_to_end max - min: bounds how far the min-gap heuristic can grow along a greedy extension
+    DevBuf<unsigned long long> d_ex_prof;
     DevBuf<uint32_t> d_ex_counters;    // wave search: num_queued, num_visited, num_pruned, steps per query
     bool exact_ready = false;
     uint32_t last_mode = 0;
@@ -456,6 +457,8 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     const uint32_t maxc = std::max<uint32_t>(costs->mismatch, (uint32_t)costs->gap_open + costs->gap_extend);
     const uint64_t n_prio64 = ((uint64_t)n + b->max_len + 2) * maxc + costs->gap_open + ((uint64_t)n + b->max_len) * costs->gap_extend + 64;
     if (n_prio64 > (1ull << 26)) return fail(POA_ERR_UNSUPPORTED, "exact replay: priority range too large for this graph / query size");
+    if (3ull * n * (((uint64_t)b->max_len + 64) & ~63ull) >= (1ull << 32))
+        return fail(POA_ERR_UNSUPPORTED, "exact replay: the visited table of one query exceeds 2^32 cells");
     const float f = (cfg && cfg->queue_entries_per_cell > 0.f) ? cfg->queue_entries_per_cell : 0.25f;
     const uint64_t pool64 = std::max<uint64_t>(256, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
     if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
@@ -759,6 +762,13 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < wp.chunk_cap) wp.chunk_cap = (uint32_t)v; }
                 wp.win = win;
                 wp.counters = b->d_ex_counters.p;
+                wp.max_lanes = 63;
+                if (const char* lv = getenv("POA_WS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) wp.max_lanes = (uint32_t)v; }
+                wp.prof = nullptr;
+                if (getenv("POA_WS_PROF")) {  // per-phase cycle counts of the wave search (diagnostics)
+                    HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
+                    wp.prof = b->d_ex_prof.p;
+                }
                 // waves per block: as many as share one staged copy of the graph within half a CU's LDS, at most 16
                 uint32_t wpb = 16;
                 if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && v <= 16) wpb = (uint32_t)v; }
@@ -892,6 +902,14 @@ int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     if (b->n_queries) HIP_TRY(hipMemcpy(out, b->d_ex_counters.p, (size_t)b->n_queries * 16, hipMemcpyDeviceToHost));
+    if (getenv("POA_WS_PROF") && b->d_ex_prof.p && b->n_queries) {
+        std::vector<unsigned long long> pr(8 * (size_t)b->n_queries);
+        HIP_TRY(hipMemcpy(pr.data(), b->d_ex_prof.p, pr.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long sum[8] = {0};
+        for (size_t i = 0; i < pr.size(); ++i) sum[i & 7] += pr[i];
+        fprintf(stderr, "[ws prof] cycles: queue+entries %llu, parallel test %llu, drop %llu, fast expand %llu (%llu), generic %llu (%llu)\n",
+                sum[0], sum[1], sum[2], sum[3], sum[5], sum[4], sum[6]);
+    }
     return POA_OK;
 }
 

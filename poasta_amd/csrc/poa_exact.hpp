@@ -165,7 +165,8 @@ public:
 
     // ---- visited table (gap_affine.rs:483-548) -----------------------------------------------
     POA_HD uint32_t* cell(uint32_t row, uint32_t off, uint32_t st) const {
-        return W.T + ex_cell_index(row, off, st, W.n_rows, W.pitch);
+        // (a query's table has 3 * n_rows * pitch < 2^32 elements: the engine plans the workspace in 32-bit element counts per query)
+        return W.T + ex_cell_index32(row, off, st, W.n_rows, W.pitch);
     }
     // Offsets beyond the row: the reference's table is a hash of tiles and takes any offset — an ends-free search that is
     // not allowed to stop at the query end opens an insertion at offset len + 1 (expand_ref_graph_end has no bound,
@@ -187,9 +188,15 @@ public:
         const uint32_t wi = off >> 6;
         if (wi >= W.wpn) { err = EX_POOL_FULL; return; }
         uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
-        const uint64_t old = *w;
-        *w = old | (1ull << (off & 63));
-        if (old == 0) W.rsum[(uint64_t)x * W.swpn + (wi >> 6)] |= 1ull << (wi & 63);
+        uint64_t* sm = W.rsum + (uint64_t)x * W.swpn + (wi >> 6);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // two ORs nobody waits for: the next reader of these words is this wave, behind them in its own memory stream
+        __hip_atomic_fetch_or(w, 1ull << (off & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_or(sm, 1ull << (wi & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+        *w |= 1ull << (off & 63);
+        *sm |= 1ull << (wi & 63);
+#endif
     }
     POA_HD bool reached_any(uint32_t row) const {  // !reached_offsets.is_empty()
         const uint64_t* s = W.rsum + (uint64_t)gld(&G.exit_idx[row]) * W.swpn;
@@ -412,6 +419,9 @@ public:
     POA_HD void queue_state(uint32_t row, uint32_t off, uint32_t st, uint32_t new_score) {
         const uint32_t pr64 = new_score + h(row, off, st);
         num_queued += 1;
+#ifdef EX_TRACE
+        printf("  push g=%u row=%u off=%u st=%u\n", new_score, row, off, st);
+#endif
         if (W.bq_desc) { bq_push(pr64, st, new_score, row, off); return; }
         if (pr64 >= W.n_prio || pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; }
         const uint32_t prio = pr64;
@@ -476,11 +486,20 @@ public:
     POA_HD void expand_mismatch(uint32_t prow, uint32_t poff, uint32_t crow, uint32_t coff, uint32_t score) {
         const uint32_t nm = score_add(score, C.x);
         if (err) return;
-        if (update_if_lower(crow, coff, EX_ST_M, nm)) queue_state(crow, coff, EX_ST_M, nm);
         const uint32_t ng = score_add(score_add(score, C.o), C.e);
         if (err) return;
-        if (update_if_lower(prow, poff + 1, EX_ST_I, ng)) queue_state(prow, poff + 1, EX_ST_I, ng);
-        if (update_if_lower(crow, poff, EX_ST_D, ng)) queue_state(crow, poff, EX_ST_D, ng);
+        if (coff >= W.pitch || poff + 1 >= W.pitch) {  // (a write past the row is a workspace overflow, see update_if_lower)
+            if (update_if_lower(crow, coff, EX_ST_M, nm)) queue_state(crow, coff, EX_ST_M, nm);
+            if (update_if_lower(prow, poff + 1, EX_ST_I, ng)) queue_state(prow, poff + 1, EX_ST_I, ng);
+            if (update_if_lower(crow, poff, EX_ST_D, ng)) queue_state(crow, poff, EX_ST_D, ng);
+            return;
+        }
+        // three different cells: read them together, then relax in the reference's order (gap_affine.rs:393-430)
+        uint32_t* pm = cell(crow, coff, EX_ST_M); uint32_t* pi = cell(prow, poff + 1, EX_ST_I); uint32_t* pd = cell(crow, poff, EX_ST_D);
+        const uint32_t vm = *pm, vi = *pi, vd = *pd;
+        if (nm < vm) { *pm = nm; queue_state(crow, coff, EX_ST_M, nm); }
+        if (ng < vi) { *pi = ng; queue_state(prow, poff + 1, EX_ST_I, ng); }
+        if (ng < vd) { *pd = ng; queue_state(crow, poff, EX_ST_D, ng); }
     }
     POA_HD void expand_all(uint32_t score, uint32_t row, uint32_t off, uint32_t st) {
         if (update_if_lower(row, off, EX_ST_M, score)) queue_state(row, off, EX_ST_M, score);
@@ -560,97 +579,73 @@ public:
     // end row, a bubble with paths of different lengths, far-away reached offsets, ends-free spans — takes the generic code:
     // same results, more round trips.  The logic below is reached.rs:38-255 specialised to tmin == tmax.
     uint32_t n_fast = 0;      // states tested on this path (statistics)
-    struct FastItem {
-        uint32_t kind;        // 0: generic path; 1: fast path applies
-        uint32_t c;           // the single successor row
-        uint32_t own;         // table value of the popped state
-        uint32_t t0, t1, t2;  // M: M[c][j+1], I[v][j+1], D[c][j];  I: M[v][j], I[v][j+1];  D: M[v][j], D[c][j]
+    // the test of one bubble whose exit lies a fixed distance ahead (tmin == tmax == t): reached bits around t and the
+    // Match scores next to t, loaded together
+    struct Probe {
+        uint32_t on;          // 0: nothing to test (no such bubble, pruning off, t beyond the query)
+        uint32_t ex, t, wi;
+        uint64_t w0, w1, w2, sum;
+        uint32_t ta, tb, tc;  // Match score of the exit row at t - 1, t, t + 1
     };
-    POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
-        F.kind = 0;
-        const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
-        const uint32_t b0 = gld(&G.nbm_off[v]), b1 = gld(&G.nbm_off[v + 1]);
-        bool fits = !C.ends_free && s1 - s0 == 1 && v != G.end_row && W.swpn == 1 && j + 2 < W.pitch && g < 0xFFFF0000u;
-        uint32_t c = 0, ex = EX_NIL, dist = 0;
-        if (fits) {
-            c = gld(&G.succ[s0]);
-            for (uint32_t k = b0; k < b1; ++k) {
-                const FlatGraph::NodeBubble b = gld(&G.nbm[k]);
-                if (b.exit_row == v) continue;
-                if (ex != EX_NIL || b.min_dist != b.max_dist) { fits = false; break; }
-                ex = b.exit_row; dist = b.min_dist;
-            }
+    // false: row v has not this shape (several bubbles ahead, or paths of different lengths through one)
+    // (pop_level: the test at a pop is subject to enable_pruning, astar.rs:155; the one inside the greedy extension is not, dfa.rs:185)
+    POA_HD bool probe_setup(uint32_t v, uint32_t j, Probe& P, bool pop_level) const {
+        uint32_t ex = EX_NIL, dist = 0;
+        for (uint32_t k = gld(&G.nbm_off[v]), k1 = gld(&G.nbm_off[v + 1]); k < k1; ++k) {
+            const FlatGraph::NodeBubble b = gld(&G.nbm[k]);
+            if (b.exit_row == v) continue;                  // reached.rs:56-58
+            if (ex != EX_NIL || b.min_dist != b.max_dist) return false;
+            ex = b.exit_row; dist = b.min_dist;
         }
-        uint8_t qj = 0;
-        if (fits && st == EX_ST_M) {
-            // a Match state goes through the greedy extension: only "first successor mismatches" is handled here
-            if (c == G.end_row || j >= L) fits = false;
-            else {
-                qj = seq[j];
-                if (gld(&G.sym[c]) == qj) fits = false;
-                if (j == 0 && L != 0 && is_symbol_equal(v, seq[0])) fits = false;  // the offset-0 special case, dfa.rs:146-167
-            }
-        }
-        if (fits) {
-        // ---- every load of the step, before any use ----
-        const uint32_t own = *cell(v, j, st);
-        uint32_t t0, t1, t2 = EX_INF;
-        if (st == EX_ST_M) { t0 = *cell(c, j + 1, EX_ST_M); t1 = *cell(v, j + 1, EX_ST_I); t2 = *cell(c, j, EX_ST_D); }
-        else if (st == EX_ST_I) { t0 = *cell(v, j, EX_ST_M); t1 = j < L ? *cell(v, j + 1, EX_ST_I) : EX_INF; }
-        else { t0 = *cell(v, j, EX_ST_M); t1 = *cell(c, j, EX_ST_D); }
-        const bool probe = C.prune && ex != EX_NIL && j + dist <= L;
-        const uint32_t t = j + dist;
-        uint64_t w0 = 0, w1 = 0, w2 = 0, sum = 0;
-        uint32_t ta = EX_INF, tb = EX_INF, tc = EX_INF;
-        uint32_t wi = 0;
-        if (probe) {
-            const uint32_t x = gld(&G.exit_idx[ex]);
-            const uint64_t* bits = W.reached + (uint64_t)x * W.wpn;
-            wi = t >> 6;
-            sum = W.rsum[(uint64_t)x * W.swpn];
-            w1 = bits[wi];
-            if (wi) w0 = bits[wi - 1];
-            if (wi + 1 < W.wpn) w2 = bits[wi + 1];
-            if (t) ta = *cell(ex, t - 1, EX_ST_M);
-            tb = *cell(ex, t, EX_ST_M);
-            tc = *cell(ex, t + 1, EX_ST_M);
-        }
-        F.kind = 1; F.c = c; F.own = own; F.t0 = t0; F.t1 = t1; F.t2 = t2;
-        n_fast += 1;
-
-        if (g > own) return 1;                      // stale (astar.rs:146)
-        if (!probe || sum == 0) return 0;           // no bubble to test / nothing reached at the exit yet (reached.rs:52-54)
-        // nearest reached offsets around t: prev < t, t itself, nxt > t
+        P.ex = ex; P.t = j + dist; P.wi = P.t >> 6;
+        P.on = ((C.prune || !pop_level) && ex != EX_NIL && P.t <= L) ? 1u : 0u;   // reached.rs:63-65: tmax > len -> can improve
+        return !(P.on && P.t + 1 >= W.pitch);                     // (the loads below read t + 1)
+    }
+    POA_HD void probe_load(Probe& P) const {
+        P.w0 = P.w1 = P.w2 = P.sum = 0; P.ta = P.tb = P.tc = EX_INF;
+        if (!P.on) return;
+        const uint32_t x = gld(&G.exit_idx[P.ex]);
+        const uint64_t* bits = W.reached + (uint64_t)x * W.wpn;
+        P.sum = W.rsum[(uint64_t)x * W.swpn];
+        P.w1 = bits[P.wi];
+        if (P.wi) P.w0 = bits[P.wi - 1];
+        if (P.wi + 1 < W.wpn) P.w2 = bits[P.wi + 1];
+        if (P.t) P.ta = *cell(P.ex, P.t - 1, EX_ST_M);
+        P.tb = *cell(P.ex, P.t, EX_ST_M);
+        P.tc = *cell(P.ex, P.t + 1, EX_ST_M);
+    }
+    // 0: can improve (not pruned); 2: pruned; 3: something the generic code has to look at (a reached cell without a score).
+    // reached.rs:38-255 specialised to tmin == tmax.
+    POA_HD uint32_t probe_decide(const Probe& P, uint32_t g, uint32_t st) {
+        if (!P.on || P.sum == 0) return 0;          // no bubble to test / nothing reached at the exit yet (reached.rs:52-54)
+        const uint32_t t = P.t, wi = P.wi, ex = P.ex;
         uint32_t prev = EX_NIL, nxt = EX_NIL;
-        const bool at_t = (w1 >> (t & 63)) & 1;
-        {
-            const uint64_t lo = (t & 63) ? (w1 & (~0ull >> (64 - (t & 63)))) : 0ull;
-            if (lo) prev = wi * 64 + 63 - (uint32_t)clz64(lo);
-            else if (wi && w0) prev = (wi - 1) * 64 + 63 - (uint32_t)clz64(w0);
-            else if (wi > 1 && (sum & (~0ull >> (64 - (wi - 1))))) prev = reached_before(ex, (wi - 1) * 64);   // far: generic lookup
-            const uint64_t hi = (t & 63) != 63 ? (w1 & (~0ull << ((t & 63) + 1))) : 0ull;
-            if (hi) nxt = wi * 64 + (uint32_t)ctz64(hi);
-            else if (wi + 1 < W.wpn && w2) nxt = (wi + 1) * 64 + (uint32_t)ctz64(w2);
-            else if (wi + 2 < W.wpn && (sum >> (wi + 2))) nxt = reached_from(ex, (wi + 2) * 64);
-        }
-        auto score_at = [&](uint32_t o2) -> uint32_t {
-            if (o2 == t) return tb;
-            if (o2 + 1 == t) return ta;
-            if (o2 == t + 1) return tc;
-            return get_score(ex, o2, EX_ST_M);
-        };
+        const bool at_t = (P.w1 >> (t & 63)) & 1;
+        const uint64_t lo = (t & 63) ? (P.w1 & (~0ull >> (64 - (t & 63)))) : 0ull;
+        if (lo) prev = wi * 64 + 63 - (uint32_t)clz64(lo);
+        else if (wi && P.w0) prev = (wi - 1) * 64 + 63 - (uint32_t)clz64(P.w0);
+        else if (wi > 1 && (P.sum & (~0ull >> (64 - (wi - 1))))) prev = reached_before(ex, (wi - 1) * 64);   // far away: generic lookup
+        const uint64_t hi = (t & 63) != 63 ? (P.w1 & (~0ull << ((t & 63) + 1))) : 0ull;
+        if (hi) nxt = wi * 64 + (uint32_t)ctz64(hi);
+        else if (wi + 1 < W.wpn && P.w2) nxt = (wi + 1) * 64 + (uint32_t)ctz64(P.w2);
+        else if (wi + 2 < W.wpn && (P.sum >> (wi + 2))) nxt = reached_from(ex, (wi + 2) * 64);
+        // scores of the two neighbours: next to t they are loaded already; else both loads go out together
+        const uint32_t lq = *cell(ex, prev != EX_NIL && prev < W.pitch ? prev : t, EX_ST_M);
+        const uint32_t rq = *cell(ex, nxt != EX_NIL && nxt < W.pitch ? nxt : t, EX_ST_M);
+        uint32_t ls = 0, rs = 0;
+        if (prev != EX_NIL) ls = prev + 1 == t ? P.ta : lq;
+        if (nxt != EX_NIL) rs = nxt == t + 1 ? P.tc : (nxt < W.pitch ? rq : EX_INF);
+        const uint32_t tb = P.tb;
+        // a reached cell holds a score; if one does not, the generic code reports what the reference would (a panic)
+        if ((prev != EX_NIL && ls == EX_INF) || (nxt != EX_NIL && rs == EX_INF) || (at_t && tb == EX_INF)) return 3;
         uint32_t mde = gld(&G.dist_min[ex]); mde = mde ? mde - 1 : 0;
-        const uint32_t ls = prev != EX_NIL ? score_at(prev) : 0, rs = nxt != EX_NIL ? score_at(nxt) : 0;
-        // a reached cell holds a score; if it does not the generic code reports what the reference would (a panic)
         bool improve;
-        if ((prev != EX_NIL && ls == EX_INF) || (nxt != EX_NIL && rs == EX_INF) || (at_t && tb == EX_INF)) { F.kind = 0; fits = false; improve = true; }
-        else
         if (at_t) {
             // the loop body of reached.rs:67-141 runs once with next == t; afterwards prev == t (reached.rs:139, :177-186)
             improve = (st == EX_ST_D && tb + C.o > g) || (prev != EX_NIL && st == EX_ST_I && ls + C.o > g);
             if (!improve) {
-                const uint32_t implicit = prev != EX_NIL ? (ls + gap_cost(EX_ST_M, t - prev) < tb ? ls + gap_cost(EX_ST_M, t - prev) : tb) : tb;
-                improve = g < implicit;
+                const uint32_t fl = prev != EX_NIL ? ls + gap_cost(EX_ST_M, t - prev) : EX_INF;
+                improve = g < (fl < tb ? fl : tb);
             }
             if (!improve && st == EX_ST_I) improve = tb + C.o > g;
         } else {
@@ -665,47 +660,112 @@ public:
             } else improve = true;
             if (!improve && prev != EX_NIL && st == EX_ST_I) improve = ls + C.o > g;
         }
-        if (fits) return improve ? 0 : 2;
-        }
-        return inspect_skip(g, v, j, st);
+        return improve ? 0 : 2;
     }
-    // the expansion of a state inspect_fast let through (F.kind == 1); true when the search ends (never on this path)
-    POA_HD void mark_reached_atomic(uint32_t row, uint32_t off) {
-        const uint32_t x = gld(&G.exit_idx[row]);
-        if (x == EX_NIL) return;
-        const uint32_t wi = off >> 6;
-        if (wi >= W.wpn) { err = EX_POOL_FULL; return; }
-        uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
-        uint64_t* sm = W.rsum + (uint64_t)x * W.swpn + (wi >> 6);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // nobody waits for these: the next reader is this wave, behind them in its own memory stream
-        __hip_atomic_fetch_or(w, 1ull << (off & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_or(sm, 1ull << (wi & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-        *w |= 1ull << (off & 63);
-        *sm |= 1ull << (wi & 63);
-#endif
-    }
-    POA_HD void process_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, const FastItem& F) {
-        if (st == EX_ST_M) mark_reached_atomic(v, j);
-        num_visited += 1;
-        if (err) return;
-        const uint32_t c = F.c;
+
+    struct FastItem {
+        uint32_t kind;        // 0: generic path; 1: expands without a greedy match; 2: Match state whose only successor matches
+        uint32_t c;           // the single successor row
+        uint32_t t0, t1, t2;  // M: M[c][j+1], I[v][j+1], D[c][j];  I: M[v][j], I[v][j+1];  D: M[v][j], D[c][j]
+    };
+    // Test of a popped state: 0 goes on to process_fast; 1 stale; 2 pruned; 3 not this shape (F.kind == 0: inspect_skip decides).
+    POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
+        F.kind = 0;
+        const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
+        if (C.ends_free || s1 - s0 != 1 || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) return 3;
+        const uint32_t c = gld(&G.succ[s0]);
+        Probe P;
+        if (!probe_setup(v, j, P, true)) return 3;
+        uint32_t kind = 1;
         if (st == EX_ST_M) {
-            // greedy extension: the only successor mismatches -> expand_mismatch (gap_affine.rs:393-430), then nothing is left
+            // a Match state goes through the greedy extension: a single successor that is not the end, query not exhausted
+            if (c == G.end_row || j >= L) return 3;
+            if (j == 0 && L != 0 && is_symbol_equal(v, seq[0])) return 3;  // the offset-0 special case, dfa.rs:146-167
+            if (gld(&G.sym[c]) == seq[j]) kind = 2;
+        }
+        // ---- every load of the step, before any use ----
+        const uint32_t own = *cell(v, j, st);
+        uint32_t t0, t1, t2 = EX_INF;
+        if (st == EX_ST_M) { t0 = *cell(c, j + 1, EX_ST_M); t1 = *cell(v, j + 1, EX_ST_I); t2 = *cell(c, j, EX_ST_D); }
+        else if (st == EX_ST_I) { t0 = *cell(v, j, EX_ST_M); t1 = j < L ? *cell(v, j + 1, EX_ST_I) : EX_INF; }
+        else { t0 = *cell(v, j, EX_ST_M); t1 = *cell(c, j, EX_ST_D); }
+        probe_load(P);
+        n_fast += 1;
+        if (g > own) return 1;                      // stale (astar.rs:146)
+        const uint32_t r = probe_decide(P, g, st);
+        if (r == 3) return 3;
+        F.kind = kind; F.c = c; F.t0 = t0; F.t1 = t1; F.t2 = t2;
+        return r;
+    }
+    // The expansion of a state inspect_fast let through.  true: the search ends here (only through the generic tail).
+    POA_HD bool process_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, const FastItem& F, ExactResult& R, uint32_t& end_score) {
+        mark_reached(v, j, st);
+        num_visited += 1;
+        if (err) return false;
+        const uint32_t c = F.c;
+        if (st == EX_ST_I) {
+            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
+            const uint32_t ns = g + C.e;
+            if (j < L && ns < F.t1) { *cell(v, j + 1, EX_ST_I) = ns; queue_state(v, j + 1, EX_ST_I, ns); }
+            return false;
+        }
+        if (st == EX_ST_D) {
+            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
+            const uint32_t ns = g + C.e;
+            if (ns < F.t1) { *cell(c, j, EX_ST_D) = ns; queue_state(c, j, EX_ST_D, ns); }
+            return false;
+        }
+        if (F.kind == 1) {
+            // the only successor mismatches -> expand_mismatch (gap_affine.rs:393-430), then the extension has nothing left
             const uint32_t nm = g + C.x, ng = g + C.o + C.e;
             if (nm < F.t0) { *cell(c, j + 1, EX_ST_M) = nm; queue_state(c, j + 1, EX_ST_M, nm); }
             if (ng < F.t1) { *cell(v, j + 1, EX_ST_I) = ng; queue_state(v, j + 1, EX_ST_I, ng); }
             if (ng < F.t2) { *cell(c, j, EX_ST_D) = ng; queue_state(c, j, EX_ST_D, ng); }
-        } else if (st == EX_ST_I) {
-            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
-            const uint32_t ns = g + C.e;
-            if (j < L && ns < F.t1) { *cell(v, j + 1, EX_ST_I) = ns; queue_state(v, j + 1, EX_ST_I, ns); }
-        } else {
-            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
-            const uint32_t ns = g + C.e;
-            if (ns < F.t1) { *cell(c, j, EX_ST_D) = ns; queue_state(c, j, EX_ST_D, ns); }
+            return false;
         }
+        // Greedy extension along single-successor rows (dfa.rs:138-250).  A parent with one successor has nothing left once
+        // that successor is taken, so it need not stay on the stack: the walk keeps only its tip.  One round trip per
+        // matched base: the tip's cell, the bubble test of the tip and the cells a mismatch would relax, all loaded together.
+        uint32_t cj = j, cc = c, tm = F.t0;
+        dfa_visited = 0; dfa_score = g;
+        for (;;) {
+            // here: cc is the single successor of cv, not the end row, cj < L, sym(cc) == seq[cj]
+            const uint32_t nj = cj + 1;
+            if (!(g < tm)) break;                          // already there with this score or better: not extended (dfa.rs:242)
+            *cell(cc, nj, EX_ST_M) = g;
+            // what the tip needs next: its own successor, its bubble test, and what a mismatch there relaxes
+            const uint32_t s0 = gld(&G.succ_off[cc]), s1 = gld(&G.succ_off[cc + 1]);
+            const uint32_t nc = s1 - s0 == 1 ? gld(&G.succ[s0]) : EX_NIL;
+            Probe P;
+            const bool shaped = probe_setup(cc, nj, P, false);
+            const bool walk_on = shaped && nc != EX_NIL && nc != G.end_row && nj < L && nj + 2 < W.pitch;
+            uint32_t n0 = EX_INF, n1 = EX_INF, n2 = EX_INF;
+            if (shaped) probe_load(P);
+            if (walk_on) { n0 = *cell(nc, nj + 1, EX_ST_M); n1 = *cell(cc, nj + 1, EX_ST_I); n2 = *cell(nc, nj, EX_ST_D); }
+            uint32_t pr = shaped ? probe_decide(P, g, EX_ST_M) : 3u;
+            if (pr == 3) pr = prune(g, cc, nj, EX_ST_M) ? 2u : 0u;
+            if (err) break;
+            if (pr == 2) { num_pruned_dfa += 1; break; }   // scored, not extended (dfa.rs:185-188)
+            mark_reached(cc, nj, EX_ST_M);
+            dfa_visited += 1;
+            if (!walk_on) {
+                // the tip is not a plain chain row: the generic extension goes on from it (its ancestors have nothing left)
+                sp = 0;
+                W.stack[sp++] = ExStackEntry{cc, nj, s0};
+                if (dfa_events(g, R, end_score)) return true;
+                break;
+            }
+            if (gld(&G.sym[nc]) != seq[nj]) {
+                const uint32_t nm = g + C.x, ng = g + C.o + C.e;
+                if (nm < n0) { *cell(nc, nj + 1, EX_ST_M) = nm; queue_state(nc, nj + 1, EX_ST_M, nm); }
+                if (ng < n1) { *cell(cc, nj + 1, EX_ST_I) = ng; queue_state(cc, nj + 1, EX_ST_I, ng); }
+                if (ng < n2) { *cell(nc, nj, EX_ST_D) = ng; queue_state(nc, nj, EX_ST_D, ng); }
+                break;
+            }
+            cj = nj; cc = nc; tm = n0;
+        }
+        num_visited += dfa_visited;
+        return false;
     }
 
     // ---- one popped state (astar.rs:141-216) ------------------------------------------------------
@@ -716,6 +776,23 @@ public:
         if (C.prune && prune(score, row, off, st)) return 2;
         return 0;
     }
+    // the events of the greedy extension that stands in W.stack[0..sp) (astar.rs:167-204); true: the search ends (R.end_* set)
+    POA_HD bool dfa_events(uint32_t score, ExactResult& R, uint32_t& end_score) {
+        for (;;) {
+            const Event ev = dfa_extend();
+            if (err || ev.kind == EV_NONE) break;
+            if (ev.kind == EV_REF_GRAPH_END) {
+                if (is_end(ev.crow, ev.coff, EX_ST_M)) { end_score = score; R.end_row = ev.crow; R.end_off = ev.coff; return true; }
+                expand_ref_graph_end(ev.prow, ev.poff, score);
+            } else if (ev.kind == EV_QUERY_END) {
+                expand_query_end(ev.poff, ev.crow, score);
+            } else {
+                expand_mismatch(ev.prow, ev.poff, ev.crow, ev.coff, score);
+            }
+            if (err) break;
+        }
+        return false;
+    }
     // everything after the stale / prune tests; true when the search ends here (R.end_* set)
     POA_HD bool process_popped(uint32_t score, uint32_t row, uint32_t off, uint32_t st, ExactResult& R, uint32_t& end_score) {
         if (is_end(row, off, st)) { num_visited += 1; end_score = score; R.end_row = row; R.end_off = off; return true; }
@@ -725,20 +802,8 @@ public:
         if (st == EX_ST_M) {
             sp = 0; dfa_visited = 0; dfa_score = score;
             W.stack[sp++] = ExStackEntry{row, off, gld(&G.succ_off[row])};
-            for (;;) {
-                const Event ev = dfa_extend();
-                if (err || ev.kind == EV_NONE) break;
-                if (ev.kind == EV_REF_GRAPH_END) {
-                    if (is_end(ev.crow, ev.coff, EX_ST_M)) { end_score = score; R.end_row = ev.crow; R.end_off = ev.coff; return true; }
-                    expand_ref_graph_end(ev.prow, ev.poff, score);
-                } else if (ev.kind == EV_QUERY_END) {
-                    expand_query_end(ev.poff, ev.crow, score);
-                } else {
-                    expand_mismatch(ev.prow, ev.poff, ev.crow, ev.coff, score);
-                }
-                if (err) break;
-            }
-            num_visited += dfa_visited;  // skipped by `break 'main` above (astar.rs:172,:205)
+            if (dfa_events(score, R, end_score)) return true;
+            num_visited += dfa_visited;  // skipped by `break 'main` (astar.rs:172,:205)
         } else {
             expand_all(score, row, off, st);
         }
@@ -797,17 +862,21 @@ public:
             const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
             uint32_t n = nb;
             ExU4 e{0, 0, 0, 0};
-            FastItem F{0, 0, 0, 0, 0, 0};
+            FastItem F{0, 0, 0, 0, 0};
             for (uint32_t i = 0; i < nb && !err; ++i) {
                 e = ch[d.n_top - i];
-                const uint32_t sk = use_fast ? inspect_fast(e.x, e.y, e.z, st, F) : inspect_skip(e.x, e.y, e.z, st);
+                uint32_t sk = use_fast ? inspect_fast(e.x, e.y, e.z, st, F) : 3u;
+                if (sk == 3) sk = inspect_skip(e.x, e.y, e.z, st);
                 if (sk == 0) { n = i; break; }
                 if (sk == 2) num_pruned += 1;
             }
             if (err) break;
             bq_drop(st, d, n < nb ? n + 1 : nb, ch[0].x);
             if (n < nb) {
-                if (F.kind) process_fast(e.x, e.y, e.z, st, F);
+#ifdef EX_TRACE
+                printf("pop g=%u row=%u off=%u st=%u kind=%u layer=%u\n", e.x, e.y, e.z, st, F.kind, layer_min);
+#endif
+                if (F.kind) found = process_fast(e.x, e.y, e.z, st, F, R, end_score);
                 else found = process_popped(e.x, e.y, e.z, st, R, end_score);
             }
         }

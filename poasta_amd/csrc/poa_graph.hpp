@@ -37,6 +37,15 @@ inline uint64_t ex_cell_index(uint32_t row, uint32_t off, uint32_t st, uint32_t 
     if (row < rows_t) return ((uint64_t)(row >> 3) * (pitch >> 3) + (off >> 3)) * 192u + st * 64u + (row & 7u) * 8u + (off & 7u);
     return 3ull * rows_t * pitch + ((uint64_t)st * (n_rows - rows_t) + (row - rows_t)) * pitch + off;
 }
+// the same index in 32-bit arithmetic, for tables of fewer than 2^32 elements (the replay kernels check that)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t ex_cell_index32(uint32_t row, uint32_t off, uint32_t st, uint32_t n_rows, uint32_t pitch) {
+    const uint32_t rows_t = n_rows & ~7u;
+    if (row < rows_t) return ((row >> 3) * (pitch >> 3) + (off >> 3)) * 192u + st * 64u + (row & 7u) * 8u + (off & 7u);
+    return 3u * rows_t * pitch + (st * (n_rows - rows_t) + (row - rows_t)) * pitch + off;
+}
 
 struct RowMeta {  // 16 bytes, one per row
     uint32_t node;        // node index in the host graph (rpos of AlignedPair)

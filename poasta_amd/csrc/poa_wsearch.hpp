@@ -29,7 +29,9 @@ struct WSearchParams {
     uint32_t* ring_global;    // null: the rings live in LDS; else [slots * 3 * win] in global memory
     uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
     uint32_t waves_per_block;
+    uint32_t max_lanes;       // entries tested per step (<= 63)
     uint32_t* counters;       // optional [4 * total]: num_queued, num_visited, num_pruned, steps (null: not kept)
+    unsigned long long* prof; // optional [8 * total] cycles: queue+entries, parallel test, drop, fast expand, generic test+expand; counts
 };
 
 __device__ __forceinline__ uint32_t ws_bcast(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
@@ -124,32 +126,46 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
     adopt(0);
     S.bq_wr = lane == 0;
 
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool prof = P.prof != nullptr;
+#define WS_TICK(k) do { if (prof) { const unsigned long long now_ = clock64(); pc[k] += now_ - t_last; t_last = now_; } } while (0)
+    unsigned long long t_last = prof ? clock64() : 0;
     while (!found && !S.err) {
         uint32_t st; BqDesc d;
         if (!S.bq_current(st, d)) { S.err = EX_PANIC; break; }  // "Could not align sequence!" (astar.rs:142-144)
-        const uint32_t nb = d.n_top;  // <= 63 entries in the top chunk: lane i takes the i-th from the top
+        const uint32_t nb = d.n_top < P.max_lanes ? d.n_top : P.max_lanes;  // <= 63 entries in the top chunk: lane i takes the i-th from the top
         const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
         const bool act = lane < nb;
         const ExU4 e = ch[act ? d.n_top - lane : 0];  // the idle lanes read slot 0: {previous chunk}
+        if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        WS_TICK(0);
         uint32_t sk = 1;
-        typename ExactSearchT<AS>::FastItem F{0, 0, 0, 0, 0, 0};
+        typename ExactSearchT<AS>::FastItem F{0, 0, 0, 0, 0};
         if (act) sk = S.inspect_fast(e.x, e.y, e.z, st, F);
-        // first entry that is neither stale nor pruned (a lane whose test hit an error stops the run as well)
-        const uint64_t stop = __ballot(act && (sk == 0 || S.err != 0));
+        // first entry that is neither stale nor pruned; an entry of another shape (sk == 3) ends the run too and is tested
+        // by its own lane below: the lanes stay on the one-round-trip path together
+        const uint64_t stop = __ballot(act && (sk == 0 || sk == 3 || S.err != 0));
+        WS_TICK(1);
         const uint32_t n = stop ? (uint32_t)__builtin_ctzll(stop) : nb;
         if (lane < n && sk == 2) S.num_pruned += 1;   // per-lane tallies, summed at the end
         if (lane > n) S.err = 0;                      // tests beyond the run are discarded with whatever they hit
         const uint32_t prev = ws_bcast(e.x, 63);      // lane 63 is never active (nb <= 63)
         S.bq_drop(st, d, n < nb ? n + 1 : nb, prev);
         steps += 1;
+        WS_TICK(2);
         if (n < nb) {
             if (lane == n && !S.err) {
                 S.bq_wr = true;
-                if (F.kind) S.process_fast(e.x, e.y, e.z, st, F);
-                else found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+                if (F.kind) found = S.process_fast(e.x, e.y, e.z, st, F, R, end_score) ? 1u : 0u;
+                else {
+                    if (sk == 3) sk = S.inspect_skip(e.x, e.y, e.z, st);
+                    if (sk == 2) S.num_pruned += 1;
+                    if (sk == 0 && !S.err) found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+                }
                 S.bq_wr = lane == 0;
             }
             adopt(n);
+            if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const uint32_t k_ = ws_bcast(F.kind, n); WS_TICK(k_ ? 3 : 4); pc[k_ ? 5 : 6] += 1; }
         }
     }
 
@@ -159,6 +175,7 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
         E.end_cell[2 * qi] = R.end_row;
         E.end_cell[2 * qi + 1] = R.end_off;
         if (P.counters) {
+            if (prof) for (int k = 0; k < 8; ++k) P.prof[8 * (uint64_t)qi + k] = pc[k];
             P.counters[4 * qi] = nq; P.counters[4 * qi + 1] = nv; P.counters[4 * qi + 2] = np; P.counters[4 * qi + 3] = steps;
         }
     }

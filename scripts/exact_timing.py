@@ -12,8 +12,13 @@ ap.add_argument("--queries", type=int, default=2000)
 ap.add_argument("--mode", default="exact")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--scale", type=float, default=1.0, help="config 2 scaled down: backbone, bubbles and query length x scale")
 args = ap.parse_args()
-g, (qseq, qoff) = W.config2(n_queries=args.queries)
+if args.scale == 1.0:
+    g, (qseq, qoff) = W.config2(n_queries=args.queries)
+else:
+    k = args.scale
+    g, (qseq, qoff) = W.scaled_linearish(int(900 * k), int(50 * k), int(25 * k), args.queries, int(1000 * k))
 costs = aligner.GapAffine(4, 2, 6)
 rb = aligner.ResidentBatch(g, qseq, qoff)
 cfg = aligner.make_config(args.mode, queue_entries_per_cell=0.25)
