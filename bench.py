@@ -4,20 +4,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed over RCCL when N > 1; launched by torch.distributed.run).
-A "step" is one pass of the hot path over the rank's resident query batch: forward (score planes)
-+ traceback + compaction, results left in HBM.  Queries are independent, so ranks share nothing on
-the data path (weak scaling: 10 000 queries per GPU == configs[2] at N = 8); after the timed region
-the results are gathered to rank 0 with one RCCL all_gather (the path's only collective).
+One process per GPU.  With N > 1 and no launcher in the environment this script starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` itself (as a child, before anything touches the
+GPU) and exits with its code; under the driver's own torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.
+A "step" is one pass of the hot path over the rank's resident query batch: forward (score planes) + traceback +
+compaction, results left in HBM.  Queries are independent, so ranks share nothing on the data path (weak scaling:
+10 000 queries per GPU == configs[2] at N = 8); after the timed region the results travel once, device to device:
+records to every rank (all_gather), alignment pairs to rank 0 (gather) — poasta_amd/dist.py, RCCL over xGMI.
 
-Rank 0 prints ONE JSON line (see the task contract) with `roofline` (dominant kernel = the forward
-pass; algorithmic bytes = 12 B per cell) and, at N = 1, `cpu_baseline` (the
-oracle's restated reference CPU path — A* + min-gap heuristic + pruning, lasagna-shaped thread
-pool — on a bounded sample of the same workload).
+Rank 0 prints ONE JSON line (task contract) with
+  roofline      the forward kernel against the ceiling that binds it (VALU issue, measured by
+                profiles/microbench/valu_issue.hip), with the HBM figures beside it: `alg_*` = SURVEY.md §8(d)'s fixed
+                12 B/cell accounting, `traffic*` = PMC bytes;
+  like_for_like the same step with u32 score planes (12 real bytes per cell: where §8(d)'s accounting is physical);
+  value_incl_d2h  the step including the device->host copy of scores, flags and pairs (SURVEY.md §8(d)'s wall time);
+  bit_exact     (N = 1) the hybrid mode — dense pass + replay of the reference's search for every query the dense pass
+                could not certify — over the whole batch: throughput and how many alignments equal the restated
+                reference's;
+  cpu_baseline  (N = 1) the restated reference CPU path on the host's cores, all physical cores and one thread.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,6 +36,35 @@ if ROOT not in sys.path:
 
 ALG_BYTES_PER_CELL = 12.0      # three u32 planes written once per cell
 HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+N_SIMD = 1024                  # 256 CUs x 4
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _load_json(*rel):
+    try:
+        with open(os.path.join(ROOT, *rel)) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def valu_ceiling():
+    """Wave-instructions per second one SIMD issues for the packed-u16 / permute / DPP instructions the forward kernels are
+    made of, at 8 resident waves (profiles/microbench/valu_issue_r02.json, measured in-kernel on an MI355X)."""
+    mb = _load_json("profiles", "microbench", "valu_issue_r02.json")
+    if not mb:
+        return None
+    rates = [r["waves_per_simd"]["8"]["simd_instr_per_s_in_kernel"] for r in mb["results"]
+             if r["op"] in ("v_pk_add_u16 clamp", "v_pk_min_u16", "v_perm_b32", "v_mov_b32_dpp row_shr:1")]
+    return sum(rates) / len(rates) if rates else None
 
 
 def main():
@@ -36,21 +74,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--queries", type=int, default=10000, help="queries per GPU")
     ap.add_argument("--length", type=int, default=1000)
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="queries timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="queries timed on the CPU baseline at all cores (-1 = the whole batch, 0 = skip baseline and bit_exact)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip like_for_like / value_incl_d2h / bit_exact (profiling runs)")
     ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank dry run on ONE GPU: every rank uses cuda:0 and the gather runs over gloo (not a measurement)")
+                    help="multi-rank dry run on ONE GPU (or none for the spawn path): every rank uses cuda:0 and the gather runs "
+                         "over gloo on CPU tensors (not a measurement)")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # no launcher: become one.  Nothing has touched the GPU yet (torch is not even imported).
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -58,7 +106,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdev = torch.device("cpu") if args.rehearse else dev  # where the tensors of the collectives live
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -69,13 +116,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from poasta_amd import aligner, workloads
+    from poasta_amd import dist as pdist
+    from poasta_amd.graph import pack_queries
 
     # ---- workload: configs[1] per GPU; rank r owns queries [r*Q, (r+1)*Q) of the seeded stream ----
     t0 = time.time()
     poa = workloads.LinearishPOA(seed=1)
     graph = poa.graph
     qs = poa.queries(args.queries, length=args.length, seed=2, first=rank * args.queries)
-    from poasta_amd.graph import pack_queries
     qseq, qoff = pack_queries(qs)
     t_gen = time.time() - t0
     costs = aligner.GapAffine(4, 2, 6)  # (mismatch, extend, open): the CLI defaults of the reference
@@ -83,7 +131,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     batch = aligner.ResidentBatch(graph, qseq, qoff, device=local_rank)  # inputs now resident in HBM
     n_rows = graph.n
-    cells_rank = int(sum(n_rows * (int(qoff[i + 1] - qoff[i]) + 1) for i in range(args.queries)))
+    cells_rank = int(n_rows * (np.diff(qoff).astype(np.int64) + 1).sum())
     bases_rank = int(qoff[-1])
 
     def barrier():
@@ -91,43 +139,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(b, k, cfg=None):
+        """k steps on batch b between barriers -> (seconds max over ranks, engine stats of those steps)."""
+        barrier()
+        b.stats()
+        t_start = time.perf_counter()
+        for _ in range(k):
+            b.run(costs, stream, cfg)
+        barrier()
+        el = time.perf_counter() - t_start
+        st_ = b.stats()  # HIP events recorded on `stream` around every kernel of the timed steps
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=torch.device("cpu") if args.rehearse else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, st_
+
     for _ in range(args.warmup):
         batch.run(costs, stream)
-    barrier()
-    batch.stats()  # drop warm-up timings
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        batch.run(costs, stream)
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    st = batch.stats()  # HIP events recorded on `stream` around every kernel of the timed steps
-    elapsed_t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if dist is not None:
-        dist.all_reduce(elapsed_t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(elapsed_t.item())
+    elapsed_max, st = timed(batch, args.steps)
 
-    # ---- result gather (the path's only exchange step): fixed-stride records to every rank ----
-    res = batch.fetch(want_pairs=(rank == 0))
+    # ---- result gather (the path's only exchange step), from the engine's result buffers in HBM ----
     gather_ms = None
-    flagged_total = int((res.flags != 0).sum())
-    score_sum = int(res.score.astype(np.uint64).sum())
+    d_score, d_flags, d_off, d_pairs = pdist.device_result_tensors(batch, dev)
+    flagged_total = int((d_flags != 0).sum().item())
+    score_sum = int((d_score.to(torch.int64) & 0xFFFFFFFF).sum().item())
+    pairs_at_root = int(d_pairs.shape[0])
     if dist is not None and not args.no_gather:
-        ptrs = batch.device_results()
-        rec = torch.stack([torch.from_numpy(res.score.astype(np.int64)), torch.from_numpy(res.flags.astype(np.int64)),
-                           torch.from_numpy((res.pair_off[1:] - res.pair_off[:-1]).astype(np.int64))], dim=1).to(cdev)
-        out = [torch.empty_like(rec) for _ in range(world)]
-        torch.cuda.synchronize()
+        if args.rehearse:
+            d_score, d_flags, d_off, d_pairs = (t.cpu() for t in (d_score, d_flags, d_off, d_pairs))
+        barrier()
         g0 = time.perf_counter()
-        dist.all_gather(out, rec)
-        torch.cuda.synchronize()
+        g_score, g_flags, g_np, g_pairs = pdist.gather_result_tensors(d_score, d_flags, d_off, d_pairs)
+        barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
-        allrec = torch.cat(out).cpu().numpy()
-        flagged_total = int((allrec[:, 1] != 0).sum())
-        score_sum = int(allrec[:, 0].sum())
-        del ptrs
+        flagged_total = int((g_flags != 0).sum().item())
+        score_sum = int(g_score.sum().item())
+        if rank == 0:
+            assert int(g_np.sum().item()) == int(g_pairs.shape[0])
+            pairs_at_root = int(g_pairs.shape[0])
+        del g_score, g_flags, g_np, g_pairs
+    del d_score, d_flags, d_off, d_pairs
+
+    # ---- device -> host copy of one step's results (SURVEY.md §8(d) counts it; `value` does not) ----
+    incl_d2h = None
+    if not args.no_extras:
+        barrier()
+        t1 = time.perf_counter()
+        batch.run(costs, stream)
+        res = batch.fetch(want_pairs=True)   # synchronises, then copies score / flags / pair_off / pairs to the host
+        dt = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if args.rehearse else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        incl_d2h = {"value": round(cells_rank * world / dt / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt * 1e3, 3),
+                    "d2h_ms": round(res.stats["ms_d2h"], 3), "d2h_bytes": int(res.pairs.nbytes + res.score.nbytes + res.flags.nbytes + res.pair_off.nbytes),
+                    "note": "one step + poa_batch_fetch (pageable host buffers), single shot"}
+    else:
+        res = batch.fetch(want_pairs=(rank == 0))
+
+    # ---- the same step with u32 planes: 12 real bytes per cell (rank-local, not part of `value`) ----
+    like = None
+    if not args.no_extras and "POA_PLANES" not in os.environ:
+        os.environ["POA_PLANES"] = "32"
+        try:
+            b32 = aligner.ResidentBatch(graph, qseq, qoff, device=local_rank)
+            b32.run(costs, stream)
+            el32, st32 = timed(b32, 2)
+            l32 = max(st32["n_forward_launches"], 1)
+            ms32 = st32["ms_forward"] / l32
+            cpl32 = cells_rank * st32["n_runs"] / l32
+            like = {"dtype": "u32", "value": round(cells_rank * world * 2 / el32 / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(el32 / 2 * 1e3, 3),
+                    "forward_launch_ms": round(ms32, 3), "hbm_bytes_written_per_cell": 12,
+                    "hbm_achieved_GBps": round(12.0 * cpl32 / (ms32 * 1e-3) / 1e9, 1),
+                    "hbm_frac": round(12.0 * cpl32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "note": "POA_PLANES=32: M, I, D stored as u32 = the reference's VisitedCellAffine; here the 12 B/cell of SURVEY.md 8(d) are real stores"}
+            b32.close()
+        finally:
+            del os.environ["POA_PLANES"]
 
     if rank == 0:
         total_cells = cells_rank * world
@@ -137,23 +227,37 @@ def main():
         launches = max(st["n_forward_launches"], 1)
         avg_launch_ms = st["ms_forward"] / launches
         cells_per_launch = cells_rank * st["n_runs"] / launches
-        achieved = ALG_BYTES_PER_CELL * cells_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("workload") == "config2" and tj.get("queries") == args.queries:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_achieved = ALG_BYTES_PER_CELL * cells_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        kc = _load_json("profiles", "kernel_counters.json") or _load_json("profiles", "hbm_traffic.json") or {}
+        same = kc.get("workload") == "config2" and kc.get("queries") == args.queries and "POA_PLANES" not in os.environ
+        traffic = kc.get("hbm_bytes_per_launch") if same else None
+        valu_insts = kc.get("sq_insts_valu_per_launch") if same else None
+        ceil_simd = valu_ceiling()
         if os.environ.get("POA_PLANES") == "32":
             kernel_name = "poa_forward_kernel<4, unsigned int>"
         elif os.environ.get("POA_COMPACT") == "0" or os.environ.get("POA_PACKED") == "0":
             kernel_name = "poa_forward_kernel<2, unsigned short>"
         else:
             kernel_name = "poa_forward_px_kernel<true>" if os.environ.get("POA_PX") != "0" else "poa_forward_packed_kernel<2>"
+        roof = {"kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3), "launches_timed": launches,
+                "cells_per_launch": int(cells_per_launch),
+                "alg_bytes_per_cell": ALG_BYTES_PER_CELL, "alg_achieved_GBps": round(alg_achieved, 1),
+                "alg_frac_of_hbm_peak": round(alg_achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "traffic_frac": None if not traffic else round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "traceback_ms_per_step": round(st["ms_traceback"] / max(st["n_runs"], 1), 3)}
+        if valu_insts and ceil_simd:
+            ach = valu_insts / (avg_launch_ms * 1e-3) / 1e9
+            peak = ceil_simd * N_SIMD / 1e9
+            roof.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
+                         "note": "VALU issue binds this kernel: achieved = SQ_INSTS_VALU per launch (PMC, profiles/kernel_counters.json) / "
+                                 "launch time; peak = measured issue rate of the packed-u16 / permute / DPP instructions it consists of, "
+                                 "8 waves per SIMD (profiles/microbench).  HBM beside it: alg_* is SURVEY.md 8(d)'s fixed 12 B/cell "
+                                 "(the engine stores ~2.7 B/cell, so that ratio exceeds 1 by construction), traffic* are PMC bytes"})
+        else:
+            roof.update({"bound": "hbm", "achieved": round(alg_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(alg_achieved / HBM_PEAK_GBPS, 4),
+                         "note": "12 B/cell accounting of SURVEY.md 8(d) (no PMC instruction count for this configuration in profiles/)"})
         line = {
             "metric": "Gcells/sec (aligned bases/sec in config), gap-affine POA alignment, 1k-node POA x 10k x 1 kbp queries per GPU",
             "value": round(gcells, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,25 +268,23 @@ def main():
                                    "1%% del, seed 2), Global, mismatch 4 / open 6 / extend 2" % (args.queries, args.length),
                        "rows": n_rows, "queries_per_gpu": args.queries, "query_len": args.length,
                        "cells_per_step": total_cells, "aligned_bases_per_sec": round(total_bases * args.steps / elapsed_max, 1),
-                       "step": "forward planes + traceback + compaction, inputs and results resident in HBM",
+                       "step": "dense mode: forward planes + traceback + compaction, inputs and results resident in HBM; scores are "
+                               "the reference's, alignments are certified-or-flagged (see bit_exact for the identical mode)",
                        "arithmetic": "saturating packed u16 min-plus (exact: the optimal score is bounded by 3.8 k here; results are u32)",
                        "flagged_queries": flagged_total, "score_checksum": score_sum,
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                       "gather": None if gather_ms is None else "records all_gather + pairs gather to rank 0 from the engine's HBM result buffers (%d pairs at rank 0)" % pairs_at_root,
                        "workload_gen_s": round(t_gen, 2), "plane_chunks": st["n_chunks"]},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3),
-                         "launches_timed": launches, "cells_per_launch": int(cells_per_launch),
-                         "alg_bytes_per_cell": ALG_BYTES_PER_CELL,
-                         "note": "B_alg is fixed at 12 B/cell (the reference's three u32 score planes, SURVEY.md 8d); the "
-                                 "engine stores u16 M + 4-bit codes + partial D (~3 B/cell, see traffic), so frac > 1 is by "
-                                 "construction: the kernel is VALU-issue bound (DESIGN.md 6), not HBM bound",
-                         "traceback_ms_per_step": round(st["ms_traceback"] / max(st["n_runs"], 1), 3)},
+            "roofline": roof,
         }
-        if world == 1 and args.cpu_sample > 0:
-            sample = qs[:min(args.cpu_sample, len(qs))]
-            line["cpu_baseline"], A = cpu_baseline(graph, sample, n_rows)
-            line["bit_exact_check"] = bit_exact_check(graph, sample, res, A, costs)
+        if like is not None:
+            line["like_for_like"] = like
+        if incl_d2h is not None:
+            line["value_incl_d2h"] = incl_d2h
+        if world == 1 and args.cpu_sample != 0 and not args.no_extras:
+            n_cpu = len(qs) if args.cpu_sample < 0 else min(args.cpu_sample, len(qs))
+            line["cpu_baseline"], A = cpu_baseline(graph, qs[:n_cpu], n_rows)
+            line["bit_exact"] = bit_exact(batch, costs, stream, res, A, n_cpu, cells_rank, flagged_total)
         print(json.dumps(line), flush=True)
     batch.close()
     if dist is not None:
@@ -190,49 +292,108 @@ def main():
         dist.destroy_process_group()
 
 
+def _cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("physical id"):
+                    pid = ln.split(":", 1)[1].strip()
+                elif ln.startswith("core id"):
+                    cid = ln.split(":", 1)[1].strip()
+                elif not ln.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, (len(phys) or usable), usable
+
+
 def cpu_baseline(graph, qs, n_rows):
-    """The oracle's restated reference CPU path on the host cores (reported baseline, not the target)."""
+    """The oracle's restated reference CPU path (A* + min-gap heuristic + superbubble pruning + backtrace, one aligner per
+    thread over a shared graph and bubble index: `lasagna`'s shape) on the host: all physical cores this process may use,
+    and one thread.  A reported baseline, not the target."""
     from oracle import pyoracle
     from poasta_amd.graph import pack_queries
-    threads = max(1, min(16, os.cpu_count() or 1))
+    model, phys, usable = _cpu_info()
+    max_threads = max(1, min(phys, usable))
     og = pyoracle.OracleGraph.from_csr(graph.as_dict())
     qseq, qoff = pack_queries(qs)
-    og.astar_batch(qseq[:int(qoff[8])], qoff[:9], threads=threads, want_pairs=False)  # warm (bubble index, pages)
+    og.astar_batch(qseq[:int(qoff[8])], qoff[:9], threads=min(max_threads, 8), want_pairs=False)  # warm (bubble index, pages)
+    # the port's thread pool does not scale linearly (allocator, NUMA): take the thread count that is fastest on a slice
+    sweep = {}
+    ns = min(len(qs), 2048)
+    cand = sorted({max_threads, max(1, max_threads // 2), max(1, max_threads // 4), min(16, max_threads)}, reverse=True)
+    for t in cand:
+        t0 = time.perf_counter()
+        og.astar_batch(qseq[:int(qoff[ns])], qoff[:ns + 1], pyoracle.Costs(4, 6, 2), pyoracle.H_MINGAP, True, threads=t, want_pairs=True)
+        sweep[t] = time.perf_counter() - t0
+    threads = min(sweep, key=sweep.get)
     t0 = time.perf_counter()
     A = og.astar_batch(qseq, qoff, pyoracle.Costs(4, 6, 2), pyoracle.H_MINGAP, True, threads=threads,
                        want_pairs=True, want_counters=True)
     dt = time.perf_counter() - t0
-    cells = sum(n_rows * (int(qoff[i + 1] - qoff[i]) + 1) for i in range(len(qs)))
-    return ({"value": round(cells / dt / 1e9, 4), "unit": "Gcells/s (matrix-equivalent)", "cores": threads,
-            "kind": "port",
-            "sample": "%d queries of the same workload, A* + min-gap heuristic + superbubble pruning + backtrace "
-                      "(C++ restatement of the reference CPU path), %d threads, %.2f s wall" % (len(qs), threads, dt),
-            "aligned_bases_per_sec": round(int(qoff[-1]) / dt, 1),
-            "visited_states_per_sec": round(float(A["counters"][:, 1].sum()) / dt, 1),
-            "host_cpus": os.cpu_count()}, A)
+    cells = int(n_rows * (qoff[1:] - qoff[:-1] + 1).astype("int64").sum())
+    # one thread, on a bounded slice (about 10 ms per query)
+    n1 = min(len(qs), 384)
+    t1 = time.perf_counter()
+    og.astar_batch(qseq[:int(qoff[n1])], qoff[:n1 + 1], pyoracle.Costs(4, 6, 2), pyoracle.H_MINGAP, True, threads=1, want_pairs=True)
+    dt1 = time.perf_counter() - t1
+    cells1 = int(n_rows * (qoff[1:n1 + 1] - qoff[:n1] + 1).astype("int64").sum())
+    return ({"value": round(cells / dt / 1e9, 4), "unit": "Gcells/s (matrix-equivalent)", "cores": threads, "kind": "port",
+             "sample": "%d queries of the same workload, A* + min-gap heuristic + superbubble pruning + backtrace (C++ restatement of "
+                       "the reference CPU path, -O3), %d threads (fastest of the sweep below; %d physical cores usable), %.2f s wall" % (len(qs), threads, max_threads, dt),
+             "thread_sweep_gcells": {str(t): round(int(n_rows * (qoff[1:ns + 1] - qoff[:ns] + 1).astype("int64").sum()) / v / 1e9, 4) for t, v in sweep.items()},
+             "cpu_model": model, "physical_cores": phys, "usable_cpus": usable,
+             "aligned_bases_per_sec": round(int(qoff[-1]) / dt, 1),
+             "visited_states_per_sec": round(float(A["counters"][:, 1].sum()) / dt, 1),
+             "single_thread": {"value": round(cells1 / dt1 / 1e9, 5), "unit": "Gcells/s (matrix-equivalent)", "cores": 1,
+                               "sample": "%d queries, %.2f s wall" % (n1, dt1), "ms_per_query": round(dt1 / n1 * 1e3, 3)}}, A)
 
 
-def bit_exact_check(graph, qs, dense_res, A, costs):
-    """Outside the timed region: the same sample against the restated reference — scores of the timed dense pass, and
-    alignments of the hybrid mode (dense pass + replay of the reference's search where the dense pass found ties)."""
+def bit_exact(batch, costs, stream, dense_res, A, n_checked, cells_rank, dense_flagged):
+    """Outside the timed region: hybrid mode over the WHOLE resident batch (dense pass, then the replay of the reference's
+    search for every query the dense pass flagged), timed, and compared with the restated reference on the queries the
+    CPU baseline ran."""
     from oracle import pyoracle
     from poasta_amd import aligner
-    n = len(qs)
-    ok = A["status"] == 0
-    score_equal = int(sum(1 for i in range(n) if ok[i] and int(dense_res.score[i]) == int(A["score"][i])))
-    dense_identical = int(sum(1 for i in range(n) if ok[i] and dense_res.raw_alignment(i) == pyoracle.batch_alignment(A, i)))
-    k = min(n, 512)
-    al = aligner.PoastaAligner(aligner.AffineMinGapCost(costs), mode="hybrid")
-    al.align_batch(graph, qs[:8])  # warm (replay workspace)
+    cfg = aligner.make_config("hybrid", queue_entries_per_cell=0.25)
+    batch.run(costs, stream, cfg)   # warm (replay workspace)
+    batch.stats()
     t0 = time.perf_counter()
-    hy = al.align_batch(graph, qs[:k])
+    batch.run(costs, stream, cfg)
+    st = batch.stats()
     dt = time.perf_counter() - t0
-    hybrid_identical = int(sum(1 for i in range(k) if ok[i] and int(hy.score[i]) == int(A["score"][i]) and
-                               hy.raw_alignment(i) == pyoracle.batch_alignment(A, i)))
-    return {"against": "restated reference (A*, min-gap, pruning), %d queries" % n, "dense_scores_equal": score_equal,
-            "dense_alignments_identical": dense_identical, "dense_flagged_as_tied": int((dense_res.flags[:n] != 0).sum()),
-            "hybrid_queries": k, "hybrid_alignments_identical": hybrid_identical, "hybrid_seconds": round(dt, 3),
-            "hybrid_replayed": int(hy.stats["n_exact"])}
+    hy = batch.fetch(want_pairs=True)
+    ok = A["status"] == 0
+    n = n_checked
+    dense_identical = int(sum(1 for i in range(n) if ok[i] and dense_res.raw_alignment(i) == pyoracle.batch_alignment(A, i)))
+    scores_equal = int(sum(1 for i in range(n) if ok[i] and int(hy.score[i]) == int(A["score"][i])))
+    identical = int(sum(1 for i in range(n) if ok[i] and int(hy.score[i]) == int(A["score"][i]) and
+                        hy.raw_alignment(i) == pyoracle.batch_alignment(A, i)))
+    out = {"mode": "hybrid", "value": round(cells_rank / dt / 1e9, 3), "unit": "Gcells/s", "seconds": round(dt, 4),
+           "queries": len(hy.score), "replayed": int(hy.stats["n_exact"]), "flagged_fraction": round(dense_flagged / max(len(hy.score), 1), 4),
+           "ms_dense_pass": round(st["ms_forward"] + st["ms_traceback"], 3), "ms_replay": round(st["ms_exact"], 3),
+           "checked_against": "restated reference (A*, min-gap, pruning), %d queries" % n,
+           "scores_equal": scores_equal, "alignments_identical": identical,
+           "dense_mode_alignments_identical": dense_identical,
+           "overflow": int(((hy.flags & 0x40) != 0).sum())}
+    try:
+        sc = batch.search_counters()
+        sel = sc[:, 3] > 0
+        if sel.any():
+            out.update(replay_pops_mean=round(float(sc[sel, 0].mean()), 1), replay_steps_mean=round(float(sc[sel, 3].mean()), 1))
+    except Exception:
+        pass
+    return out
 
 
 if __name__ == "__main__":

@@ -3,10 +3,11 @@
 The reference's only parallelism is `lasagna`'s worker pool over independent reads against one
 immutable graph (/root/reference/src/bin/lasagna.rs:246-268).  The same independence is used here:
 queries are split into contiguous blocks, one per rank (one process per GPU), the graph is replicated
-(KB..MB), and nothing is exchanged during the DP.  After compute, results travel once:
-fixed-stride records {score, flags, n_pairs} with `all_gather`, then the variable-length alignment
-pairs with a padded `all_gather` (sizes are known from the records).  With backend "nccl" this is
-RCCL over xGMI; tests run the same code on "gloo".
+(KB..MB), and nothing is exchanged during the DP.  After compute, results travel once (SURVEY.md §8(e)):
+fixed-stride records {score, flags, n_pairs} to every rank with `all_gather`, then the variable-length alignment
+pairs to rank 0 with `gather` (sizes are known from the records).  The tensors are the engine's own result buffers in
+HBM (`ResidentBatch.device_results`, wrapped without a copy), so with backend "nccl" the exchange is RCCL over xGMI,
+device to device; the gloo tests and `bench.py --rehearse` run the same function on CPU tensors.
 """
 import numpy as np
 
@@ -18,41 +19,91 @@ def shard_range(n_total, rank, world):
     return first, max(0, min(per, n_total - first))
 
 
-def gather_results(score, flags, pair_off, pairs, device=None, group=None):
-    """All ranks call this with their shard's results (numpy arrays as returned by BatchResult).
-    Returns (score, flags, pair_off, pairs) of the whole batch in rank order on EVERY rank
-    (all_gather keeps the call symmetric; rank 0 is the consumer in bench.py)."""
+class _DevArray:
+    """A device buffer the engine owns, described through __cuda_array_interface__ so that torch aliases it."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_result_tensors(batch, device):
+    """score i32[n], flags i32[n], pair_off i64[n+1], pairs i32[pair_off[n], 2] as torch tensors ALIASING the engine's result
+    buffers of the last run (valid until the next run / close).  The u32 / u64 values are carried bit for bit in the signed
+    types NCCL moves."""
+    import torch
+    n = batch.n
+    ptrs = batch.device_results()
+    torch.cuda.synchronize(device)
+    if n == 0:
+        z32 = torch.zeros(0, dtype=torch.int32, device=device)
+        return z32, z32.clone(), torch.zeros(1, dtype=torch.int64, device=device), torch.zeros((0, 2), dtype=torch.int32, device=device)
+    score = torch.as_tensor(_DevArray(ptrs["score"], (n,), "<i4"), device=device)
+    flags = torch.as_tensor(_DevArray(ptrs["flags"], (n,), "<i4"), device=device)
+    pair_off = torch.as_tensor(_DevArray(ptrs["pair_off"], (n + 1,), "<i8"), device=device)
+    n_pairs = int(pair_off[n].item())
+    if n_pairs:
+        pairs = torch.as_tensor(_DevArray(ptrs["pairs"], (n_pairs, 2), "<i4"), device=device)
+    else:
+        pairs = torch.zeros((0, 2), dtype=torch.int32, device=device)
+    return score, flags, pair_off, pairs
+
+
+def gather_result_tensors(score, flags, pair_off, pairs, group=None, dst=0):
+    """Every rank calls this with its shard's results as tensors (all on one device type: HBM for nccl, CPU for gloo).
+    Returns on EVERY rank the records of the whole batch in rank order, (score, flags, n_pairs) int64 tensors, and on `dst`
+    also the concatenated pairs [sum n_pairs, 2] (None elsewhere).  Two collectives: all_gather (records), gather (pairs)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    dev = device if device is not None else torch.device("cpu")
-    n_local = len(score)
-    npairs = (np.asarray(pair_off[1:], np.int64) - np.asarray(pair_off[:-1], np.int64))
+    rank = dist.get_rank(group)
+    dev = score.device
+    n_local = int(score.shape[0])
+    npairs = (pair_off[1:] - pair_off[:-1]).to(torch.int64)
     # 1) how many queries / pairs each rank holds
-    meta = torch.tensor([n_local, int(npairs.sum())], dtype=torch.int64, device=dev)
+    meta = torch.tensor([n_local, int(pairs.shape[0])], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     counts = [int(m[0]) for m in metas]
     pcounts = [int(m[1]) for m in metas]
     max_n, max_p = max(counts + [1]), max(pcounts + [1])
-    # 2) fixed-stride records
+    # 2) fixed-stride records to every rank
     rec = torch.zeros((max_n, 3), dtype=torch.int64, device=dev)
     if n_local:
-        rec[:n_local, 0] = torch.from_numpy(np.asarray(score, np.int64)).to(dev)
-        rec[:n_local, 1] = torch.from_numpy(np.asarray(flags, np.int64)).to(dev)
-        rec[:n_local, 2] = torch.from_numpy(npairs).to(dev)
+        rec[:n_local, 0] = score.to(torch.int64) & 0xFFFFFFFF
+        rec[:n_local, 1] = flags.to(torch.int64) & 0xFFFFFFFF
+        rec[:n_local, 2] = npairs
     recs = [torch.zeros_like(rec) for _ in range(world)]
     dist.all_gather(recs, rec, group=group)
-    # 3) alignment pairs (padded to the largest shard)
-    pbuf = torch.full((max_p, 2), -1, dtype=torch.int64, device=dev)
-    if len(pairs):
-        pbuf[:len(pairs)] = torch.from_numpy(np.asarray(pairs, np.int64)).to(dev)
-    pbufs = [torch.zeros_like(pbuf) for _ in range(world)]
-    dist.all_gather(pbufs, pbuf, group=group)
-    all_rec = torch.cat([recs[r][:counts[r]] for r in range(world)]).cpu().numpy()
-    all_pairs = torch.cat([pbufs[r][:pcounts[r]] for r in range(world)]).cpu().numpy()
-    g_score = all_rec[:, 0].astype(np.uint32)
-    g_flags = all_rec[:, 1].astype(np.uint32)
-    g_off = np.zeros(len(all_rec) + 1, np.uint64)
-    g_off[1:] = np.cumsum(all_rec[:, 2])
-    return g_score, g_flags, g_off, all_pairs.astype(np.uint32)
+    all_rec = torch.cat([recs[r][:counts[r]] for r in range(world)])
+    # 3) alignment pairs to the consumer (padded to the largest shard: gather wants equal shapes)
+    pbuf = torch.zeros((max_p, 2), dtype=torch.int32, device=dev)
+    if pairs.shape[0]:
+        pbuf[:pairs.shape[0]] = pairs
+    bufs = [torch.zeros_like(pbuf) for _ in range(world)] if rank == dst else None
+    dist.gather(pbuf, bufs, dst=dst, group=group)
+    all_pairs = torch.cat([bufs[r][:pcounts[r]] for r in range(world)]) if rank == dst else None
+    return all_rec[:, 0], all_rec[:, 1], all_rec[:, 2], all_pairs
+
+
+def gather_results(score, flags, pair_off, pairs, device=None, group=None):
+    """numpy in, numpy out (the whole batch on every rank's records; pairs on every rank for symmetry with the tests):
+    (score u32, flags u32, pair_off u64, pairs u32[., 2])."""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+    s = t(np.asarray(score, np.uint32), np.int32)
+    f = t(np.asarray(flags, np.uint32), np.int32)
+    o = t(np.asarray(pair_off, np.uint64), np.int64)
+    p = t(np.asarray(pairs, np.uint32).reshape(-1, 2), np.int32)
+    g_score, g_flags, g_np, g_pairs = gather_result_tensors(s, f, o, p, group=group, dst=0)
+    # hand the pairs to every rank (tests read them on rank 0; the symmetric call keeps the helper simple)
+    world = dist.get_world_size(group)
+    total = torch.tensor([int(g_np.sum())], dtype=torch.int64, device=dev)
+    buf = g_pairs if dist.get_rank(group) == 0 else torch.zeros((int(total.item()), 2), dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.broadcast(buf, src=0, group=group)
+    g_off = np.zeros(len(g_np) + 1, np.uint64)
+    g_off[1:] = np.cumsum(g_np.cpu().numpy())
+    return (g_score.cpu().numpy().astype(np.uint32), g_flags.cpu().numpy().astype(np.uint32), g_off,
+            buf.cpu().numpy().view(np.uint32).reshape(-1, 2))

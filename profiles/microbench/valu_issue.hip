@@ -1,0 +1,103 @@
+// Micro-benchmark behind DESIGN.md's VALU ceiling: how many wave64 VALU instructions one SIMD of an MI355X (gfx950) issues per
+// second, for the instruction kinds the forward kernels are made of, at 1 / 2 / 4 / 8 resident waves per SIMD.
+// Each wave runs ITER x 32 instructions over 8 independent registers (dependency distance 8 >= the pipeline depth), nothing
+// else; blocks of 256 threads put one wave on each SIMD of a CU, W blocks per CU give W waves per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip && ./valu_issue > valu_issue.json
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int ITER = 4000;
+
+#define REP8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
+#define REP32(OP) REP8(OP) REP8(OP) REP8(OP) REP8(OP)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void bench(uint32_t* out, unsigned long long* cyc, uint32_t k) {
+    uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < ITER; ++i) {
+        if (KIND == 0) {
+#define OP(r) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(r) : "v"(k));
+            REP32(OP)
+#undef OP
+        } else if (KIND == 1) {
+#define OP(r) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(r) : "v"(k));
+            REP32(OP)
+#undef OP
+        } else if (KIND == 2) {
+#define OP(r) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(k), "v"(0x05040100u));
+            REP32(OP)
+#undef OP
+        } else if (KIND == 3) {
+#define OP(r) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r));
+            REP32(OP)
+#undef OP
+        } else if (KIND == 4) {
+#define OP(r) asm volatile("v_pk_add_u16 %0, %0, %1 clamp" : "+v"(r) : "v"(k));
+            REP32(OP)
+#undef OP
+        } else {
+#define OP(r) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(k));
+            REP32(OP)
+#undef OP
+        }
+    }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if ((threadIdx.x & 63) == 0) { cyc[2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = t1 - t0; cyc[2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = w1 - w0; }
+}
+
+template <int KIND>
+int run(const char* name, int cus, uint32_t* d_out, unsigned long long* d_cyc, bool first) {
+    const int ws[4] = {1, 2, 4, 8};
+    printf("%s  {\"op\": \"%s\", \"waves_per_simd\": {", first ? "" : ",\n", name);
+    for (int wi = 0; wi < 4; ++wi) {
+        const int W = ws[wi], blocks = cus * W;
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 3u);  // warm
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 3u);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> cyc(2 * (size_t)blocks * 4);
+        CHECK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+        double c = 0, w = 0;
+        for (size_t i = 0; i < cyc.size(); i += 2) { c += (double)cyc[i]; w += (double)cyc[i + 1]; }
+        c /= (double)(cyc.size() / 2); w /= (double)(cyc.size() / 2);
+        const double instr_per_wave = (double)ITER * 32.0;
+        // per SIMD: W waves x instr_per_wave instructions in the wave's lifetime (in-kernel clock) resp. the launch (events)
+        const double wall_s = w / 100e6;  // wall_clock64: 100 MHz
+        printf("%s\"%d\": {\"launch_ms\": %.4f, \"wave_cycles_clock64\": %.0f, \"wave_us_wallclock\": %.2f, "
+               "\"simd_instr_per_s_in_kernel\": %.4g, \"simd_instr_per_s_launch\": %.4g, \"clock64_per_instr_per_wave\": %.3f}",
+               wi ? ", " : "", W, ms, c, wall_s * 1e6, W * instr_per_wave / wall_s, W * instr_per_wave / (ms * 1e-3), c / instr_per_wave);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    printf("}}");
+    return 0;
+}
+
+int main() {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    int clk_khz = 0;
+    (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
+    uint32_t* d_out; unsigned long long* d_cyc;
+    CHECK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4));
+    CHECK(hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * 2 * 8));
+    printf("{\"device_cus\": %d, \"clock_rate_khz\": %d, \"instr_per_wave\": %d, \"results\": [\n", cus, clk_khz, ITER * 32);
+    if (run<0>("v_pk_add_u16", cus, d_out, d_cyc, true)) return 1;
+    if (run<4>("v_pk_add_u16 clamp", cus, d_out, d_cyc, false)) return 1;
+    if (run<1>("v_pk_min_u16", cus, d_out, d_cyc, false)) return 1;
+    if (run<2>("v_perm_b32", cus, d_out, d_cyc, false)) return 1;
+    if (run<3>("v_mov_b32_dpp row_shr:1", cus, d_out, d_cyc, false)) return 1;
+    if (run<5>("v_add_u32", cus, d_out, d_cyc, false)) return 1;
+    printf("\n]}\n");
+    return 0;
+}
