@@ -4,7 +4,8 @@
 //   poasta::aligner::{PoastaAligner, AlignedPair, AstarResult}      /root/reference/src/aligner/mod.rs:40-146, astar.rs:81-90
 //   poasta::aligner::scoring::{GapAffine, AlignmentType}            src/aligner/scoring/gap_affine.rs:20-30, scoring/mod.rs:50-62
 //   poasta::aligner::config::{AffineMinGapCost, AffineDijkstra}     src/aligner/config.rs:49,:104
-//   poasta::graphs::poa::POAGraph (the parts a batch driver needs)  src/graphs/poa.rs:85-134, :323-363, :384-471
+//   poasta::graphs::poa::POAGraph (construction, graph update)      src/graphs/poa.rs:85-363, :384-471
+//   poasta::io::{load_graph_from_fasta_msa, poa_graph_to_fasta}     src/io/graph.rs:36-103, src/io/fasta.rs:19-156
 //   poasta::io::{load_graph_from_gfa, GraphSegments}                src/io/graph.rs:103-227, src/io/gfa.rs:233-360
 //   poasta::io::gaf::{alignment_to_gaf, GAFRecord, NodeSegmentResolver}   src/io/gaf.rs:11-304
 // Where the reference panics, this layer throws poasta::PoastaError.  All alignment work happens in the
@@ -14,6 +15,8 @@
 #include <cstdint>
 #include <cctype>
 #include <fstream>
+#include <map>
+#include <set>
 #include <memory>
 #include <optional>
 #include <sstream>
@@ -31,9 +34,21 @@ struct PoastaError : std::runtime_error {
 };
 
 // =====================================================================================================
-namespace graphs {
+namespace graphs { using NodeIndex = uint32_t; }
 
-using NodeIndex = uint32_t;
+namespace aligner {
+struct AlignedPair {  // alignment.rs:4-38
+    std::optional<graphs::NodeIndex> rpos;
+    std::optional<size_t> qpos;
+    bool is_aligned() const { return rpos && qpos; }
+    bool is_indel() const { return !is_aligned(); }
+    bool is_deletion() const { return !rpos && qpos; }   // sic: the reference's naming (alignment.rs:30-32)
+    bool is_insertion() const { return rpos && !qpos; }  // sic (alignment.rs:34-36)
+};
+using Alignment = std::vector<AlignedPair>;
+}  // namespace aligner
+
+namespace graphs {
 
 // POAGraph with petgraph's adjacency semantics: add_edge prepends, so successors()/predecessors() yield the
 // most recently added edge first.  Node 0 = start '#', node 1 = end '$'.
@@ -51,35 +66,103 @@ public:
     uint8_t get_symbol(NodeIndex v) const { return symbol_[v]; }
     bool is_symbol_equal(NodeIndex v, uint8_t s) const { return v == end_node() || symbol_[v] == s; }  // poa.rs:463-465
 
+    struct POAEdgeData { size_t weight = 0; std::vector<size_t> sequence_ids; };   // poa.rs:58-79
+    struct Sequence { std::string name; NodeIndex start_node; };                    // poa.rs:21-37
+    std::vector<Sequence> sequences;
+    const std::vector<NodeIndex>& get_aligned_nodes(NodeIndex v) const { return aligned_nodes_[v]; }
+    const POAEdgeData* edge_data(NodeIndex s, NodeIndex t) const {
+        auto it = edges_.find(((uint64_t)s << 32) | t);
+        return it == edges_.end() ? nullptr : &it->second;
+    }
+
     NodeIndex add_node(uint8_t sym) {
-        symbol_.push_back(sym); succ_.emplace_back(); pred_.emplace_back();
+        symbol_.push_back(sym); succ_.emplace_back(); pred_.emplace_back(); aligned_nodes_.emplace_back();
         flat_.reset();
         return (NodeIndex)symbol_.size() - 1;
     }
-    // POAGraph::add_edge (poa.rs:118-134): an existing edge keeps its position
-    void add_edge(NodeIndex s, NodeIndex t) {
+    // POAGraph::add_edge (poa.rs:118-134): an existing edge keeps its position, gets the sequence id and the weight added
+    void add_edge(NodeIndex s, NodeIndex t, size_t sequence_id = 0, size_t weight = 0) {
+        POAEdgeData& d = edges_[((uint64_t)s << 32) | t];
+        d.sequence_ids.push_back(sequence_id);
+        d.weight += weight;
         if (std::find(succ_[s].begin(), succ_[s].end(), t) != succ_[s].end()) return;
         succ_[s].insert(succ_[s].begin(), t);
         pred_[t].insert(pred_[t].begin(), s);
         flat_.reset();
     }
     // poa.rs:136-169; returns (first, last)
-    std::optional<std::pair<NodeIndex, NodeIndex>> add_nodes_for_sequence(const std::string& seq, size_t start, size_t end) {
+    std::optional<std::pair<NodeIndex, NodeIndex>> add_nodes_for_sequence(const std::string& seq, size_t start, size_t end,
+                                                                        const std::vector<size_t>* weights = nullptr) {
         if (start == end) return std::nullopt;
         NodeIndex first = 0, prev = 0;
         for (size_t pos = start; pos < end; ++pos) {
             NodeIndex cur = add_node((uint8_t)seq[pos]);
-            if (pos == start) first = cur; else add_edge(prev, cur);
+            if (pos == start) first = cur;
+            else add_edge(prev, cur, sequences.size(), weights ? (*weights)[pos - 1] + (*weights)[pos] : 0);
             prev = cur;
         }
         return std::make_pair(first, prev);
     }
+    // add_alignment_with_weights (poa.rs:171-321): the graph update of `poasta align` — consumes the Alignment verbatim
+    void add_alignment_with_weights(const std::string& name, const std::string& seq, const aligner::Alignment* alignment,
+                                    const std::vector<size_t>& weights) {
+        if (seq.size() != weights.size()) throw PoastaError("WeightsUnequalSize");
+        if (!alignment) {
+            if (seq.empty()) sequences.push_back(Sequence{name, start_node()});
+            else sequences.push_back(Sequence{name, add_nodes_for_sequence(seq, 0, seq.size(), &weights)->first});
+            post_process();
+            return;
+        }
+        std::vector<size_t> valid_ix;
+        for (const auto& e : *alignment) if (e.qpos && *e.qpos < seq.size()) valid_ix.push_back(*e.qpos);
+        if (valid_ix.empty()) {
+            if (seq.empty()) { sequences.push_back(Sequence{name, start_node()}); post_process(); return; }
+            throw PoastaError("InvalidAlignment");
+        }
+        const size_t first = valid_ix.front(), last = valid_ix.back();
+        auto nodes_unaligned_begin = add_nodes_for_sequence(seq, 0, first, &weights);
+        std::optional<NodeIndex> prev;
+        if (nodes_unaligned_begin) prev = nodes_unaligned_begin->second;
+        const auto nodes_unaligned_end = add_nodes_for_sequence(seq, last + 1, seq.size(), &weights);
+        for (const auto& ap : *alignment) {
+            if (!ap.qpos) continue;
+            const size_t q = *ap.qpos;
+            const uint8_t qsymbol = (uint8_t)seq[q];
+            NodeIndex curr;
+            if (ap.rpos) {
+                const NodeIndex r = *ap.rpos;
+                if (symbol_[r] == qsymbol) curr = r;
+                else {
+                    // aligned to a node with another symbol: reuse a node of that column with this symbol, else make one
+                    std::optional<NodeIndex> found;
+                    for (NodeIndex other : aligned_nodes_[r]) if (symbol_[other] == qsymbol) { found = other; break; }
+                    if (found) curr = *found;
+                    else {
+                        const NodeIndex nn = add_node(qsymbol);
+                        const std::vector<NodeIndex> others = aligned_nodes_[r];
+                        for (NodeIndex o : others) { aligned_nodes_[o].push_back(nn); aligned_nodes_[nn].push_back(o); }
+                        aligned_nodes_[r].push_back(nn);
+                        aligned_nodes_[nn].push_back(r);
+                        curr = nn;
+                    }
+                }
+            } else {
+                curr = add_node(qsymbol);  // an insertion
+            }
+            if (!nodes_unaligned_begin) nodes_unaligned_begin = std::make_pair(curr, curr);
+            if (prev) add_edge(*prev, curr, sequences.size(), weights[q - 1] + weights[q]);
+            prev = curr;
+        }
+        if (nodes_unaligned_end) add_edge(*prev, nodes_unaligned_end->first, sequences.size(), weights[last] + weights[last + 1]);
+        sequences.push_back(Sequence{name, nodes_unaligned_begin->first});
+        post_process();
+    }
     // poa.rs:323-363
     void post_process() {
         const NodeIndex s = start_node(), e = end_node();
-        for (NodeIndex v : std::vector<NodeIndex>(succ_[s])) pred_[v].erase(std::find(pred_[v].begin(), pred_[v].end(), s));
+        for (NodeIndex v : std::vector<NodeIndex>(succ_[s])) { pred_[v].erase(std::find(pred_[v].begin(), pred_[v].end(), s)); edges_.erase(((uint64_t)s << 32) | v); }
         succ_[s].clear();
-        for (NodeIndex v : std::vector<NodeIndex>(pred_[e])) succ_[v].erase(std::find(succ_[v].begin(), succ_[v].end(), e));
+        for (NodeIndex v : std::vector<NodeIndex>(pred_[e])) { succ_[v].erase(std::find(succ_[v].begin(), succ_[v].end(), e)); edges_.erase(((uint64_t)v << 32) | e); }
         pred_[e].clear();
         const NodeIndex n = (NodeIndex)symbol_.size();
         for (NodeIndex v = 0; v < n; ++v)
@@ -113,8 +196,12 @@ public:
 
 private:
     std::vector<uint8_t> symbol_;
-    std::vector<std::vector<NodeIndex>> succ_, pred_;
-    mutable std::shared_ptr<Flat> flat_;
+    std::vector<std::vector<NodeIndex>> succ_, pred_, aligned_nodes_;
+    std::map<uint64_t, POAEdgeData> edges_;   // start / end edges carry no data (poa.rs:73-78)
+    mutable std::shared_ptr<Flat> flat_;      // the device copy: rebuilt from the trait view after a graph update (O(N + E), host)
+public:
+    // used by io::load_graph_from_fasta_msa (it wires aligned_nodes itself, graph.rs:71-85)
+    void link_aligned_nodes(NodeIndex a, NodeIndex b) { aligned_nodes_[a].push_back(b); aligned_nodes_[b].push_back(a); }
 };
 
 }  // namespace graphs
@@ -154,16 +241,6 @@ inline const AlignmentType AlignmentType::Global{};
 
 struct AffineMinGapCost { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_MINGAP; explicit AffineMinGapCost(GapAffine c) : costs(c) {} };
 struct AffineDijkstra { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_DIJKSTRA; explicit AffineDijkstra(GapAffine c) : costs(c) {} };
-
-struct AlignedPair {  // alignment.rs:4-38
-    std::optional<graphs::NodeIndex> rpos;
-    std::optional<size_t> qpos;
-    bool is_aligned() const { return rpos && qpos; }
-    bool is_indel() const { return !is_aligned(); }
-    bool is_deletion() const { return !rpos && qpos; }   // sic: the reference's naming (alignment.rs:30-32)
-    bool is_insertion() const { return rpos && !qpos; }  // sic (alignment.rs:34-36)
-};
-using Alignment = std::vector<AlignedPair>;
 
 struct AstarResult {  // astar.rs:81-90 (+ the exactness certificate of the dense pass)
     uint32_t score = 0;
@@ -310,6 +387,105 @@ inline POAGraphFromGFA load_graph_from_gfa(const std::string& path) {
     std::ifstream f(path);
     if (!f) throw PoastaError("could not open " + path);
     return load_graph_from_gfa(f);
+}
+
+
+// load_graph_from_fasta_msa (src/io/graph.rs:36-103): per column one node per distinct symbol, '-' skipped, each row threads
+// an edge (weight 2) from its previous node; post_process at the end.  records = (name, gapped row).
+inline graphs::POAGraph load_graph_from_fasta_msa(const std::vector<std::pair<std::string, std::string>>& records) {
+    graphs::POAGraph graph;
+    std::vector<std::vector<graphs::NodeIndex>> nodes_per_col;
+    for (size_t seq_id = 0; seq_id < records.size(); ++seq_id) {
+        const std::string& chars = records[seq_id].second;
+        if (chars.size() > nodes_per_col.size()) nodes_per_col.resize(chars.size());
+        std::optional<graphs::NodeIndex> prev;
+        for (size_t col = 0; col < chars.size(); ++col) {
+            const uint8_t c = (uint8_t)chars[col];
+            if (c == '-') continue;
+            std::optional<graphs::NodeIndex> node;
+            for (graphs::NodeIndex v : nodes_per_col[col]) if (graph.get_symbol(v) == c) { node = v; break; }
+            if (!node) {
+                node = graph.add_node(c);
+                for (graphs::NodeIndex other : nodes_per_col[col]) graph.link_aligned_nodes(other, *node);
+                nodes_per_col[col].push_back(*node);
+            }
+            if (prev) graph.add_edge(*prev, *node, seq_id, 2);
+            else graph.sequences.push_back(graphs::POAGraph::Sequence{records[seq_id].first, *node});
+            prev = node;
+        }
+    }
+    graph.post_process();
+    return graph;
+}
+
+// poa_graph_to_fasta (src/io/fasta.rs:69-156) with fasta_aln_for_seq (:19-67): columns by a depth-first post-order over the
+// graph in which aligned nodes share a column; each sequence is then walked along the edges that carry its id.  Kept with the
+// reference's leading-gap arithmetic (`node_col.saturating_sub(1) - last_col`, last_col starting at 0: tests/io_fasta.rs:19
+// asserts "---AC" beside "ACGT--").
+inline std::string poa_graph_to_fasta(const graphs::POAGraph& graph) {
+    using graphs::NodeIndex;
+    std::map<NodeIndex, size_t> node_to_column;
+    struct Frame { NodeIndex node; std::vector<NodeIndex> succ; };
+    std::vector<Frame> stack;
+    stack.push_back(Frame{graph.start_node(), graph.successors(graph.start_node())});
+    std::set<NodeIndex> visited;
+    std::vector<NodeIndex> rev_postorder;
+    while (!stack.empty()) {
+        std::optional<NodeIndex> child;
+        auto& it = stack.back().succ;
+        while (!it.empty()) { const NodeIndex s = it.back(); it.pop_back(); if (!visited.count(s)) { child = s; break; } }
+        if (child) {
+            visited.insert(*child);
+            std::vector<NodeIndex> successors = graph.successors(*child);
+            for (NodeIndex aln : graph.get_aligned_nodes(*child))
+                if (!visited.count(aln)) {
+                    visited.insert(aln);
+                    const auto& more = graph.successors(aln);
+                    successors.insert(successors.end(), more.begin(), more.end());
+                }
+            stack.push_back(Frame{*child, std::move(successors)});
+        } else {
+            rev_postorder.push_back(stack.back().node);
+            stack.pop_back();
+        }
+    }
+    std::reverse(rev_postorder.begin(), rev_postorder.end());
+    size_t curr_col = 0, max_col = 0;
+    for (NodeIndex n : rev_postorder) {
+        if (n == graph.start_node() || n == graph.end_node()) continue;
+        if (!node_to_column.count(n)) {
+            node_to_column[n] = curr_col;
+            for (NodeIndex a : graph.get_aligned_nodes(n)) node_to_column[a] = curr_col;
+            max_col = curr_col;
+            curr_col += 1;
+        }
+    }
+    std::string out;
+    for (size_t seq_id = 0; seq_id < graph.sequences.size(); ++seq_id) {
+        std::string row;
+        std::optional<NodeIndex> curr = graph.sequences[seq_id].start_node;
+        size_t last_col = 0;
+        bool empty_seq = false;
+        while (curr) {
+            auto col = node_to_column.find(*curr);
+            if (col == node_to_column.end()) { empty_seq = true; break; }  // an empty sequence starts at the start node
+            const size_t node_col = col->second;
+            row.append((node_col ? node_col - 1 : 0) - last_col, '-');
+            row.push_back((char)graph.get_symbol(*curr));
+            std::optional<NodeIndex> next;
+            for (NodeIndex t : graph.successors(*curr)) {   // the LAST out-edge carrying this id wins (no break, fasta.rs:47-56)
+                const auto* d = graph.edge_data(*curr, t);
+                if (d && std::binary_search(d->sequence_ids.begin(), d->sequence_ids.end(), seq_id)) next = t;
+            }
+            curr = next;
+            last_col = node_col;
+        }
+        if (empty_seq) row.clear();
+        else if (!node_to_column.empty()) row.append(max_col - last_col, '-');
+        out += ">" + graph.sequences[seq_id].name + "\n";
+        for (size_t p2 = 0; p2 < row.size(); p2 += 80) out += row.substr(p2, 80) + "\n";   // noodles' writer wraps at 80
+    }
+    return out;
 }
 
 // NodeSegmentResolver (src/io/gaf.rs:11-55): (segment index, position in segment) of a node; the reference

@@ -355,19 +355,24 @@ def read_fasta(path):
     return [(n, s) for n, s in recs]
 
 
-def sequential_poa(records, costs=None, heuristic=H_MINGAP, prune=True, graph=None):
+def sequential_poa(records, costs=None, heuristic=H_MINGAP, prune=True, graph=None, alignments=None):
     """`poasta align` (src/bin/poasta.rs:163-236): the first read seeds the graph, every other read is aligned
-    (Global) and added with add_alignment_with_weights.  Returns (graph, [score per aligned read])."""
+    (Global) and added with add_alignment_with_weights.  Returns (graph, [score per aligned read]); `alignments`, a list,
+    receives (name, seq, alignment-or-None) per read."""
     costs = costs or Costs()
     g = graph or OracleGraph.new_poa()
     scores = []
     for name, seq in records:
         if g.n == 2:  # graph.is_empty()
             g.add_alignment(name, seq, None)
+            if alignments is not None:
+                alignments.append((name, seq, None))
         else:
             r = g.astar_align(seq, costs, heuristic, prune)
             scores.append(r["score"])
             g.add_alignment(name, seq, r["alignment"])
+            if alignments is not None:
+                alignments.append((name, seq, r["alignment"]))
     return g, scores
 
 

@@ -1,0 +1,135 @@
+// poasta_align_amd — C++ twin of the reference's sequential POA construction `poasta align [-I graph.msa.fa] reads.fa -O fasta`
+// (/root/reference/src/bin/poasta.rs:163-236, :276-496): the first read seeds the graph, every further read is aligned to the
+// graph as it stands (Global, gap-affine, defaults -n 4 -g 6 -e 2: poasta.rs:123-140) and added with
+// add_alignment_with_weights (src/graphs/poa.rs:171-321); the result is written as a FASTA MSA (src/io/fasta.rs:69-156).
+// Every alignment comes from the gfx950 library (one-query batches: the graph changes after every read, so this caller
+// does not shard — DESIGN.md §7); `--mode hybrid` (default) returns the reference's own tie-breaks, which the graph
+// update consumes verbatim.
+//
+//   poasta_align_amd align [-n MISMATCH] [-g OPEN] [-e EXTEND] [-I graph.msa.fa] [-o OUT] [--mode dense|exact|hybrid]
+//                          [--device N] [--alignments FILE] READS.fa
+//   poasta_align_amd replay ALIGNMENTS.txt          (no GPU: graph update + export from recorded alignments)
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "../../include/poasta_amd.hpp"
+
+using namespace poasta;
+
+static std::vector<std::pair<std::string, std::string>> read_fasta(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw PoastaError("could not open " + path);
+    std::vector<std::pair<std::string, std::string>> out;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            const size_t sp = line.find_first_of(" \t");
+            out.push_back({line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1), ""});
+        } else if (!out.empty()) out.back().second += line;
+    }
+    return out;
+}
+
+// ALIGNMENTS.txt: per read "name<TAB>sequence<TAB>n|-" followed by n lines "rpos qpos" (-1 = None); n == "-": no alignment
+static int replay(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw PoastaError("could not open " + path);
+    graphs::POAGraph graph;
+    std::string first;
+    std::getline(f, first);
+    if (first.rfind("msa", 0) == 0) {   // "msa<TAB>k": k records "name<TAB>row" seed the graph
+        const size_t k = std::stoul(first.substr(4));
+        std::vector<std::pair<std::string, std::string>> recs;
+        for (size_t i = 0; i < k; ++i) { std::string l; std::getline(f, l); const size_t t = l.find('\t'); recs.push_back({l.substr(0, t), l.substr(t + 1)}); }
+        graph = io::load_graph_from_fasta_msa(recs);
+        first.clear();
+    }
+    std::string line = first;
+    while (!line.empty() || std::getline(f, line)) {
+        if (line.empty()) continue;
+        const size_t t1 = line.find('\t'), t2 = line.find('\t', t1 + 1);
+        const std::string name = line.substr(0, t1), seq = line.substr(t1 + 1, t2 - t1 - 1), cnt = line.substr(t2 + 1);
+        const std::vector<size_t> weights(seq.size(), 1);
+        if (cnt == "-") graph.add_alignment_with_weights(name, seq, nullptr, weights);
+        else {
+            aligner::Alignment aln;
+            for (size_t i = 0, n = std::stoul(cnt); i < n; ++i) {
+                long long r, q;
+                f >> r >> q;
+                aligner::AlignedPair ap;
+                if (r >= 0) ap.rpos = (graphs::NodeIndex)r;
+                if (q >= 0) ap.qpos = (size_t)q;
+                aln.push_back(ap);
+            }
+            std::string rest; std::getline(f, rest);
+            graph.add_alignment_with_weights(name, seq, &aln, weights);
+        }
+        line.clear();
+    }
+    std::cout << io::poa_graph_to_fasta(graph);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc >= 3 && std::strcmp(argv[1], "replay") == 0) return replay(argv[2]);
+        if (argc < 3 || std::strcmp(argv[1], "align") != 0) {
+            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6] [-e 2] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--device 0] [--alignments file] reads.fa\n"
+                                 "       poasta_align_amd replay alignments.txt\n");
+            return 2;
+        }
+        int mismatch = 4, open = 6, extend = 2, device = 0;
+        std::string out_path, msa_path, aln_path, mode = "hybrid";
+        std::vector<std::string> pos;
+        for (int i = 2; i < argc; ++i) {
+            const std::string a = argv[i];
+            auto need = [&](const char* what) { if (i + 1 >= argc) throw PoastaError(std::string("missing value for ") + what); return std::string(argv[++i]); };
+            if (a == "-n") mismatch = std::stoi(need("-n"));
+            else if (a == "-g") open = std::stoi(need("-g"));
+            else if (a == "-e") extend = std::stoi(need("-e"));
+            else if (a == "-o") out_path = need("-o");
+            else if (a == "-I" || a == "--graph") msa_path = need("-I");
+            else if (a == "--mode") mode = need("--mode");
+            else if (a == "--device") device = std::stoi(need("--device"));
+            else if (a == "--alignments") aln_path = need("--alignments");
+            else pos.push_back(a);
+        }
+        if (pos.size() != 1) throw PoastaError("expected one FASTA of reads");
+        const aligner::Mode m = mode == "dense" ? aligner::Mode::Dense : (mode == "exact" ? aligner::Mode::Exact : aligner::Mode::Hybrid);
+        graphs::POAGraph graph;
+        if (!msa_path.empty()) graph = io::load_graph_from_fasta_msa(read_fasta(msa_path));
+        // GapAffine::new(mismatch, extend, open): the reference's argument order (gap_affine.rs:27)
+        aligner::PoastaAligner<aligner::AffineMinGapCost> al(aligner::AffineMinGapCost(aligner::GapAffine((uint8_t)mismatch, (uint8_t)extend, (uint8_t)open)),
+                                                             aligner::AlignmentType::Global, device, m);
+        std::ofstream alog;
+        if (!aln_path.empty()) alog.open(aln_path);
+        for (const auto& rec : read_fasta(pos[0])) {
+            const std::vector<size_t> weights(rec.second.size(), 1);
+            if (graph.is_empty()) {
+                graph.add_alignment_with_weights(rec.first, rec.second, nullptr, weights);   // poasta.rs:209-211
+                if (alog) alog << rec.first << '\t' << rec.second << "\t-\n";
+            } else {
+                const aligner::AstarResult r = al.align(graph, rec.second);                   // poasta.rs:214
+                std::fprintf(stderr, "Aligned '%s' (len=%zu) - Score: %u, Alignment length: %zu, flags 0x%x\n", rec.first.c_str(),
+                             rec.second.size(), r.score, r.alignment.size(), r.flags);
+                if (alog) {
+                    alog << rec.first << '\t' << rec.second << '\t' << r.alignment.size() << '\n';
+                    for (const auto& ap : r.alignment)
+                        alog << (ap.rpos ? (long long)*ap.rpos : -1LL) << ' ' << (ap.qpos ? (long long)*ap.qpos : -1LL) << '\n';
+                }
+                graph.add_alignment_with_weights(rec.first, rec.second, &r.alignment, weights);   // poasta.rs:226
+            }
+        }
+        const std::string fasta = io::poa_graph_to_fasta(graph);
+        if (out_path.empty()) std::cout << fasta;
+        else { std::ofstream o(out_path); o << fasta; }
+        return 0;
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "poasta_align_amd: %s\n", ex.what());
+        return 1;
+    }
+}

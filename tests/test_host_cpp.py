@@ -158,3 +158,84 @@ def test_lasagna_amd_gaf_matches_restated_reference(driver, oracle, tmp_path):
     # dense mode: same scores (AS:i) for every read
     dense = subprocess.check_output([driver, "align", GFA, str(fa)]).decode().strip().splitlines()
     assert [l.split("\t")[-1] for l in dense] == [l.split("\t")[-1] for l in want]
+
+
+# ------------------------------------------------------------------------------------------------
+# Graph update + MSA import / export of the C++ host mirror: POAGraph::add_alignment_with_weights
+# (src/graphs/poa.rs:171-321), load_graph_from_fasta_msa (src/io/graph.rs:36-103), poa_graph_to_fasta (src/io/fasta.rs:69-156).
+ALIGN_DRIVER = os.path.join(ROOT, "poasta_amd", "poasta_align_amd")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _replay(driver_dir, tmp_path, alignments, msa=None):
+    path = str(tmp_path / "replay.txt")
+    with open(path, "w") as f:
+        if msa:
+            f.write("msa\t%d\n" % len(msa))
+            for n, r in msa:
+                f.write("%s\t%s\n" % (n, r))
+        for name, seq, aln in alignments:
+            if aln is None:
+                f.write("%s\t%s\t-\n" % (name, seq))
+            else:
+                f.write("%s\t%s\t%d\n" % (name, seq, len(aln)))
+                for r, q in aln:
+                    f.write("%d %d\n" % (-1 if r == 0xFFFFFFFF else r, -1 if q == 0xFFFFFFFF else q))
+    return subprocess.check_output([ALIGN_DRIVER, "replay", path]).decode()
+
+
+def test_cpp_graph_update_and_export_kats(driver, tmp_path):
+    """The reference's own asserted strings (tests/io_fasta.rs:4-34, src/io/fasta.rs:165-209) through the C++ mirror."""
+    assert _replay(driver, tmp_path, [("seq1", "AC", None), ("seq2", "ACGT", None)]) == ">seq1\n---AC\n>seq2\nACGT--\n"
+    assert _replay(driver, tmp_path, [("empty", "", None)]) == ">empty\n"
+    N = 0xFFFFFFFF
+    assert _replay(driver, tmp_path, [("seq1", "ACG", None), ("seq2", "AG", [(2, 0), (3, N), (4, 1)])]) == ">seq1\nACG\n>seq2\nA-G\n"
+
+
+def test_cpp_graph_update_matches_oracle_on_fixture_builds(driver, oracle, tmp_path):
+    """Sequential POA builds of the reference's fixtures: the alignments come from the oracle, the graph update and the MSA
+    export run in the C++ mirror; the MSA must equal the oracle's own (same alignments, independent restatement)."""
+    for fa in ("test_from_abpoa.fa", "test2_from_abpoa.fa"):
+        alns = []
+        g, _ = oracle.sequential_poa(oracle.read_fasta(os.path.join(GOLD, fa)), oracle.Costs(4, 6, 2), alignments=alns)
+        assert _replay(driver, tmp_path, alns) == g.to_fasta()
+    msa = oracle.read_fasta(os.path.join(GOLD, "small_test.input.fa"))
+    alns = []
+    g = oracle.OracleGraph.from_fasta_msa(msa)
+    g, _ = oracle.sequential_poa(oracle.read_fasta(os.path.join(GOLD, "small_test.query.fa")), oracle.Costs(4, 6, 2), graph=g, alignments=alns)
+    out = _replay(driver, tmp_path, alns, msa=msa)
+    assert out == g.to_fasta()
+    assert out.splitlines()[5] == "-----TTGTCAACATCAGTA"   # small_test.truth.fa row 3 up to the export's leading-gap quirk
+    # random reads against a growing graph: co-optimal tie-breaks, SNP columns (aligned_nodes), insertions
+    rng = np.random.Generator(np.random.PCG64(11))
+    base = rng.integers(0, 4, size=60)
+    recs = []
+    for i in range(8):
+        s = base.copy()
+        for _ in range(4):
+            p = int(rng.integers(0, len(s)))
+            k = int(rng.integers(0, 3))
+            s = np.concatenate([s[:p], [int(rng.integers(0, 4))], s[p + (k != 1):]]) if k else np.delete(s, p)
+        recs.append(("r%d" % i, "".join("ACGT"[x] for x in s)))
+    alns = []
+    g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2), alignments=alns)
+    assert _replay(driver, tmp_path, alns) == g.to_fasta()
+
+
+@pytest.mark.gpu
+def test_gpu_sequential_poa_build_equals_oracle_msa(driver, oracle, tmp_path):
+    """BASELINE.json configs[0] end to end on the engine: `poasta align`-shaped driver, every read aligned on the GPU in
+    hybrid mode (the reference's own tie-breaks), graph updated on the host, MSA exported — byte-identical to the MSA the
+    oracle's sequential build gives (tests/test_oracle_msa.py says what that MSA is pinned by)."""
+    for fa in ("test_from_abpoa.fa", "test2_from_abpoa.fa"):
+        g, _ = oracle.sequential_poa(oracle.read_fasta(os.path.join(GOLD, fa)), oracle.Costs(4, 6, 2))
+        out = subprocess.check_output([ALIGN_DRIVER, "align", os.path.join(GOLD, fa)], stderr=subprocess.DEVNULL).decode()
+        assert out == g.to_fasta(), fa
+    g = oracle.OracleGraph.from_fasta_msa(oracle.read_fasta(os.path.join(GOLD, "small_test.input.fa")))
+    g, _ = oracle.sequential_poa(oracle.read_fasta(os.path.join(GOLD, "small_test.query.fa")), oracle.Costs(4, 6, 2), graph=g)
+    out = subprocess.check_output([ALIGN_DRIVER, "align", "-I", os.path.join(GOLD, "small_test.input.fa"),
+                                   os.path.join(GOLD, "small_test.query.fa")], stderr=subprocess.DEVNULL).decode()
+    assert out == g.to_fasta()
+    truth = [l for l in open(os.path.join(GOLD, "small_test.truth.fa")).read().splitlines() if not l.startswith(">")]
+    rows = [l for l in out.splitlines() if not l.startswith(">")]
+    assert rows[:2] == truth[:2] and rows[2] == truth[2][1:]   # the reference-held MSA, up to the export's leading-gap quirk
