@@ -15,6 +15,8 @@
 //   DepthFirstGreedyAlignment  src/aligner/dfa.rs:86-251
 //   astar_alignment            src/aligner/astar.rs:108-226
 //   PoastaAligner::align       src/aligner/mod.rs:69-145
+//   two-piece affine model     src/aligner/scoring/gap_affine_2piece.rs:19-133 (costs), :292-516 (edges), :639-794,
+//                              :944-1043 (backtrace), :1049-1115 (queue layer) — selected by Costs::two_piece
 //
 // Parity pin: the reference cannot be compiled in this container (Rust, no
 // toolchain), so this restatement is pinned by the reference's own known-answer
@@ -24,6 +26,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <deque>
 #include <set>
 #include <stdexcept>
@@ -58,15 +61,33 @@ inline Score score_sub(Score s, uint32_t rhs) {
     return r;
 }
 
-enum AlignState : uint8_t { ST_M = 0, ST_D = 1, ST_I = 2 };  // aln_graph.rs:8-14
+enum AlignState : uint8_t { ST_M = 0, ST_D = 1, ST_I = 2, ST_D2 = 3, ST_I2 = 4 };  // aln_graph.rs:8-14
 
 struct Costs {  // GapAffine, gap_affine.rs:20-30.  NB ctor order in the reference: (mismatch, extend, open)
     uint8_t mismatch, gap_open, gap_extend;
-    // gap_affine.rs:68-80
+    // GapAffine2Piece (gap_affine_2piece.rs:19-33; ctor order (mismatch, extend1, open1, extend2, open2)): gap_open /
+    // gap_extend are the first piece, these the second
+    uint8_t gap_open2 = 0, gap_extend2 = 0;
+    bool two_piece = false;
+    // gap_affine.rs:68-80  /  gap_affine_2piece.rs:99-127
     size_t gap_cost(AlignState st, size_t length) const {
         if (length == 0) return 0;
-        size_t open = (st == ST_M) ? gap_open : 0;
-        return open + length * (size_t)gap_extend;
+        if (!two_piece) {
+            size_t open = (st == ST_M) ? gap_open : 0;
+            return open + length * (size_t)gap_extend;
+        }
+        const size_t cost1 = (size_t)gap_open + length * (size_t)gap_extend;
+        const size_t cost2 = (size_t)gap_open2 + length * (size_t)gap_extend2;
+        if (st == ST_I || st == ST_D) return cost1;
+        if (st == ST_I2 || st == ST_D2) return cost2;
+        return std::min(cost1, cost2);
+    }
+    // gap_affine_2piece.rs:36-66
+    size_t breakpoint() const {
+        if (gap_extend == gap_extend2) return gap_open <= gap_open2 ? (size_t)-1 : 0;
+        const size_t den = (size_t)(gap_extend - gap_extend2);
+        if (gap_open2 >= gap_open) return (size_t)(gap_open2 - gap_open) / den;
+        return ((size_t)(gap_open - gap_open2) + den - 1) / den;
     }
 };
 
@@ -81,7 +102,7 @@ struct AlnNode { uint32_t node; uint32_t offset; };
 // FxHashMap — a generous CPU baseline).
 struct VisitedStorage {
     static constexpr uint32_t B = 8;
-    struct Tile { Score m[B][B], i[B][B], d[B][B]; };
+    struct Tile { Score m[B][B], i[B][B], d[B][B], i2[B][B], d2[B][B]; };
     std::vector<uint32_t> node_ranks;
     uint32_t n_oblocks = 0;
     std::vector<int32_t> tile_ix;
@@ -110,7 +131,13 @@ struct VisitedStorage {
         }
         Tile& tl = tiles[t];
         uint32_t r = rank & (B - 1), c = a.offset & (B - 1);
-        return st == ST_M ? &tl.m[r][c] : (st == ST_I ? &tl.i[r][c] : &tl.d[r][c]);
+        switch (st) {
+            case ST_M: return &tl.m[r][c];
+            case ST_I: return &tl.i[r][c];
+            case ST_D: return &tl.d[r][c];
+            case ST_I2: return &tl.i2[r][c];
+            default: return &tl.d2[r][c];
+        }
     }
     // gap_affine.rs:483-500
     inline Score get_score(const AlnNode& a, AlignState st) const {
@@ -132,17 +159,20 @@ struct VisitedStorage {
 struct QueuedItem { Score score; AlnNode node; AlignState state; };
 
 struct QueueLayer {
-    std::vector<std::pair<Score, AlnNode>> m, i, d;
-    bool empty() const { return m.empty() && d.empty() && i.empty(); }
+    std::vector<std::pair<Score, AlnNode>> m, i, d, i2, d2;
+    bool empty() const { return m.empty() && d.empty() && i.empty() && d2.empty() && i2.empty(); }
     void queue(const QueuedItem& it) {
-        (it.state == ST_M ? m : it.state == ST_I ? i : d).push_back({it.score, it.node});
+        auto& v = it.state == ST_M ? m : it.state == ST_I ? i : it.state == ST_D ? d : it.state == ST_I2 ? i2 : d2;
+        v.push_back({it.score, it.node});
     }
-    // gap_affine.rs:954-966: M stack, else D stack, else I stack — LIFO each
+    // gap_affine.rs:954-966: M stack, else D stack, else I stack — LIFO each;
+    // gap_affine_2piece.rs:1072-1097: M, D1, D2, I1, I2 (the second-piece stacks stay empty in the one-piece model)
     bool pop(QueuedItem& out) {
-        if (!m.empty()) { out = {m.back().first, m.back().second, ST_M}; m.pop_back(); return true; }
-        if (!d.empty()) { out = {d.back().first, d.back().second, ST_D}; d.pop_back(); return true; }
-        if (!i.empty()) { out = {i.back().first, i.back().second, ST_I}; i.pop_back(); return true; }
-        return false;
+        auto take = [&](std::vector<std::pair<Score, AlnNode>>& v, AlignState st) {
+            if (v.empty()) return false;
+            out = {v.back().first, v.back().second, st}; v.pop_back(); return true;
+        };
+        return take(m, ST_M) || take(d, ST_D) || take(d2, ST_D2) || take(i, ST_I) || take(i2, ST_I2);
     }
 };
 
@@ -372,7 +402,8 @@ public:
         if (!aln_type.ends_free) return st == ST_M && a.node == g.end && (size_t)a.offset == seq_len;
         bool q_ok;
         const Bound& qe = aln_type.qry_free_end;
-        if (qe.kind == BOUND_UNBOUNDED) q_ok = a.offset > 0 || seq_len == 0;   // sic: ANY consumed prefix may end
+        if (qe.kind == BOUND_UNBOUNDED) q_ok = costs.two_piece ? ((size_t)a.offset >= seq_len || seq_len == 0)   // gap_affine_2piece.rs:246-250
+                                                               : (a.offset > 0 || seq_len == 0);          // sic: ANY consumed prefix may end
         else if (qe.kind == BOUND_INCLUDED) q_ok = seq_len - (size_t)a.offset <= qe.v;
         else q_ok = seq_len - (size_t)a.offset < qe.v;
         bool g_ok;
@@ -419,23 +450,36 @@ public:
         Score nd = score_add(score_add(score, costs.gap_open), costs.gap_extend);
         if (visited.update_score_if_lower(del, ST_D, nd)) queue_state(c, del, ST_D, nd);
     }
-    // gap_affine.rs:307-341 (the Match arm :265-306 is unreachable from astar_alignment)
+    // gap_affine.rs:307-341 (the Match arm :265-306 is unreachable from astar_alignment);
+    // gap_affine_2piece.rs:346-431 for the two-piece model: a gap opens in the first piece (open1 + extend1), every further
+    // step either stays in its piece or moves from the first to the second (cost extend2; open2 is never charged)
     void expand_all(Ctx& c, Score score, const AlnNode& node, AlignState st) {
-        if (st == ST_I) {
-            if (visited.update_score_if_lower(node, ST_M, score)) queue_state(c, node, ST_M, score);
+        if (st == ST_M) throw RefPanic("expand_all(Match) is unreachable from astar_alignment");
+        if (visited.update_score_if_lower(node, ST_M, score)) queue_state(c, node, ST_M, score);
+        if (st == ST_I || st == ST_I2) {
             AlnNode ins{node.node, node.offset + 1};
-            Score ns = score_add(score, costs.gap_extend);
-            if ((size_t)node.offset < seq_len && visited.update_score_if_lower(ins, ST_I, ns))
-                queue_state(c, ins, ST_I, ns);
-        } else if (st == ST_D) {
-            if (visited.update_score_if_lower(node, ST_M, score)) queue_state(c, node, ST_M, score);
-            for (uint32_t s : g.succ[node.node]) {
-                AlnNode del{s, node.offset};
+            if (st == ST_I) {
                 Score ns = score_add(score, costs.gap_extend);
-                if (visited.update_score_if_lower(del, ST_D, ns)) queue_state(c, del, ST_D, ns);
+                if ((size_t)node.offset < seq_len && visited.update_score_if_lower(ins, ST_I, ns))
+                    queue_state(c, ins, ST_I, ns);
+            }
+            if (costs.two_piece) {
+                Score ns2 = score_add(score, costs.gap_extend2);
+                if ((size_t)node.offset < seq_len && visited.update_score_if_lower(ins, ST_I2, ns2))
+                    queue_state(c, ins, ST_I2, ns2);
             }
         } else {
-            throw RefPanic("expand_all(Match) is unreachable from astar_alignment");
+            for (uint32_t s : g.succ[node.node]) {
+                AlnNode del{s, node.offset};
+                if (st == ST_D) {
+                    Score ns = score_add(score, costs.gap_extend);
+                    if (visited.update_score_if_lower(del, ST_D, ns)) queue_state(c, del, ST_D, ns);
+                }
+                if (costs.two_piece) {
+                    Score ns2 = score_add(score, costs.gap_extend2);
+                    if (visited.update_score_if_lower(del, ST_D2, ns2)) queue_state(c, del, ST_D2, ns2);
+                }
+            }
         }
     }
 
@@ -505,6 +549,7 @@ public:
 
     // gap_affine.rs:550-657.  Returns false for None.
     bool get_backtrace(const AlnNode& a, AlignState st, AlnNode& out, AlignState& out_st) const {
+        if (costs.two_piece) return get_backtrace2(a, st, out, out_st);
         Score cs = visited.get_score(a, st);
         if (cs == UNVISITED) return false;
         if (st == ST_M) {
@@ -547,7 +592,51 @@ public:
         return false;
     }
 
-    // gap_affine.rs:804-915
+    // gap_affine_2piece.rs:639-794
+    bool get_backtrace2(const AlnNode& a, AlignState st, AlnNode& out, AlignState& out_st) const {
+        Score cs = visited.get_score(a, st);
+        if (cs == UNVISITED) return false;
+        const uint32_t o1 = costs.gap_open, e1 = costs.gap_extend, e2 = costs.gap_extend2;
+        if (st == ST_M) {
+            if (a.offset > 0) {
+                bool match_or_end = g.is_symbol_equal(a.node, seq[a.offset - 1]) || a.node == g.end;
+                uint32_t po = (a.node == g.end) ? a.offset : a.offset - 1;
+                for (uint32_t p : g.pred[a.node]) {
+                    Score ps = visited.get_score({p, po}, ST_M);
+                    if ((match_or_end && ps == cs) || (!match_or_end && ps == score_sub(cs, costs.mismatch))) {
+                        out = {p, po}; out_st = ST_M; return true;
+                    }
+                }
+            }
+            for (AlignState gs : {ST_D, ST_D2, ST_I, ST_I2})
+                if (visited.get_score(a, gs) == cs) { out = a; out_st = gs; return true; }
+        } else if (st == ST_D) {
+            for (uint32_t p : g.pred[a.node])
+                if (visited.get_score({p, a.offset}, ST_M) == score_sub(score_sub(cs, o1), e1)) { out = {p, a.offset}; out_st = ST_M; return true; }
+            for (uint32_t p : g.pred[a.node])
+                if (visited.get_score({p, a.offset}, ST_D) == score_sub(cs, e1)) { out = {p, a.offset}; out_st = ST_D; return true; }
+        } else if (st == ST_D2) {
+            for (uint32_t p : g.pred[a.node])
+                if (visited.get_score({p, a.offset}, ST_D) == score_sub(cs, e2)) { out = {p, a.offset}; out_st = ST_D; return true; }
+            for (uint32_t p : g.pred[a.node])
+                if (visited.get_score({p, a.offset}, ST_D2) == score_sub(cs, e2)) { out = {p, a.offset}; out_st = ST_D2; return true; }
+        } else if (st == ST_I) {
+            if (a.offset > 0) {
+                AlnNode pr{a.node, a.offset - 1};
+                if (visited.get_score(pr, ST_M) == score_sub(score_sub(cs, o1), e1)) { out = pr; out_st = ST_M; return true; }
+                if (visited.get_score(pr, ST_I) == score_sub(cs, e1)) { out = pr; out_st = ST_I; return true; }
+            }
+        } else {
+            if (a.offset > 0) {
+                AlnNode pr{a.node, a.offset - 1};
+                if (visited.get_score(pr, ST_I) == score_sub(cs, e2)) { out = pr; out_st = ST_I; return true; }
+                if (visited.get_score(pr, ST_I2) == score_sub(cs, e2)) { out = pr; out_st = ST_I2; return true; }
+            }
+        }
+        return false;
+    }
+
+    // gap_affine.rs:804-915  /  gap_affine_2piece.rs:944-1043
     std::vector<AlignedPair> backtrace(const AlnNode& end_cell) const {
         std::vector<AlignedPair> aln;
         if (seq_len == 0) return aln;
@@ -560,9 +649,11 @@ public:
         AlnNode curr; AlignState cst;
         bool ok = get_backtrace(end_cell, ST_M, curr, cst) ||
                   get_backtrace(end_cell, ST_I, curr, cst) ||
-                  get_backtrace(end_cell, ST_D, curr, cst);
+                  (costs.two_piece && get_backtrace(end_cell, ST_I2, curr, cst)) ||
+                  get_backtrace(end_cell, ST_D, curr, cst) ||
+                  (costs.two_piece && get_backtrace(end_cell, ST_D2, curr, cst));
         if (!ok) {
-            if (seq_len <= 3) {
+            if (seq_len <= 3 && !costs.two_piece) {  // (the two-piece file has this fallback commented out, :1025-1036)
                 for (size_t i = 0; i < seq_len; ++i) aln.push_back({end_cell.node, (uint32_t)i});
                 return aln;
             }
@@ -570,9 +661,9 @@ public:
         }
         AlnNode bt; AlignState bst;
         while (get_backtrace(curr, cst, bt, bst)) {
-            if (cst == ST_M && (bst == ST_I || bst == ST_D)) { curr = bt; cst = bst; continue; }
+            if (cst == ST_M && bst != ST_M) { curr = bt; cst = bst; continue; }
             if (cst == ST_M) aln.push_back({curr.node, curr.offset - 1});
-            else if (cst == ST_I) aln.push_back({NONE32, curr.offset - 1});
+            else if (cst == ST_I || cst == ST_I2) aln.push_back({NONE32, curr.offset - 1});
             else aln.push_back({curr.node, NONE32});
             if (bt.node == g.start) break;
             curr = bt; cst = bst;

@@ -17,6 +17,13 @@
 //   D[u][j] -> D[v][j]     e          gap_affine.rs:329-340 (v may be end)
 //   I/D[u][j] -> M[u][j]   0          gap_affine.rs:309,:325
 // Traceback rule: gap_affine.rs:550-657 + :804-915.
+//
+// Two-piece model (Costs::two_piece; gap_affine_2piece.rs:292-516, backtrace :639-794, :944-1043): five planes.  A gap opens
+// in the first piece exactly as above (o1 + e1); afterwards
+//   I[u][j]  -> I[u][j+1]   e1      I[u][j]  -> I2[u][j+1]   e2      I2[u][j] -> I2[u][j+1]   e2     (gap_affine_2piece.rs:352-388)
+//   D[u][j]  -> D[v][j]     e1      D[u][j]  -> D2[v][j]     e2      D2[u][j] -> D2[v][j]     e2     (:390-430)
+//   I, I2, D, D2 [u][j] -> M[u][j]  0
+// (open2 is never charged: the second piece is entered from the first.)
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -47,6 +54,7 @@ struct DenseResult {
     uint32_t n_ambiguous_steps = 0;
     // planes [row][col], row = topological rank, pitch = L+1
     std::vector<Score> M, I, D;
+    std::vector<Score> I2, D2;  // two-piece model only
     size_t rows = 0, pitch = 0;
 };
 
@@ -89,6 +97,7 @@ public:
     bool open_d(uint32_t v, const uint8_t* q, size_t L, size_t j) const { return j >= L || mm(v, q, j); }
 
     void forward(const uint8_t* q, size_t L, DenseResult& R) const {
+        if (costs.two_piece) { forward2(q, L, R); return; }
         size_t rows = row_node.size(), P = L + 1;
         R.rows = rows; R.pitch = P;
         R.M.assign(rows * P, UNVISITED); R.I.assign(rows * P, UNVISITED); R.D.assign(rows * P, UNVISITED);
@@ -137,6 +146,7 @@ public:
     // Reference traceback rule on the dense planes, evaluating EVERY test of a step so the
     // certificate (exactly one candidate, no phantom below target) can be decided.
     void traceback(const uint8_t* q, size_t L, DenseResult& R) const {
+        if (costs.two_piece) { traceback2(q, L, R); return; }
         const size_t P = R.pitch;
         const uint32_t x = costs.mismatch, o = costs.gap_open, e = costs.gap_extend;
         auto Mx = [&](uint32_t node, size_t j) { return R.M[rank[node] * P + j]; };
@@ -242,11 +252,146 @@ public:
         std::reverse(R.alignment.begin(), R.alignment.end());
     }
 
+
+    // ---- two-piece model ---------------------------------------------------------------------------------------------
+    void forward2(const uint8_t* q, size_t L, DenseResult& R) const {
+        size_t rows = row_node.size(), P = L + 1;
+        R.rows = rows; R.pitch = P;
+        for (auto* pl : {&R.M, &R.I, &R.D, &R.I2, &R.D2}) pl->assign(rows * P, UNVISITED);
+        const uint32_t x = costs.mismatch, oe = (uint32_t)costs.gap_open + costs.gap_extend, e1 = costs.gap_extend, e2 = costs.gap_extend2;
+        std::vector<Score> H(P);
+        for (size_t r = 0; r < rows; ++r) {
+            uint32_t v = row_node[r];
+            Score* Mv = &R.M[r * P]; Score* Iv = &R.I[r * P]; Score* Dv = &R.D[r * P]; Score* I2v = &R.I2[r * P]; Score* D2v = &R.D2[r * P];
+            const bool is_end = v == g.end;
+            for (size_t j = 0; j < P; ++j) {
+                Score pm = UNVISITED, pd = UNVISITED, pd2 = UNVISITED, pml = UNVISITED;
+                for (uint32_t p : g.pred[v]) {
+                    pm = std::min(pm, R.M[rank[p] * P + j]);
+                    pd = std::min(pd, R.D[rank[p] * P + j]);
+                    pd2 = std::min(pd2, R.D2[rank[p] * P + j]);
+                    if (j > 0) pml = std::min(pml, R.M[rank[p] * P + j - 1]);
+                }
+                Score d = sat_add(pd, e1);
+                if (!is_end && open_d(v, q, L, j)) d = std::min(d, sat_add(pm, oe));   // a deletion never opens INTO the end row
+                Dv[j] = d;
+                D2v[j] = std::min(sat_add(pd, e2), sat_add(pd2, e2));
+                Score diag = UNVISITED;
+                if (is_end) diag = pm;                                                 // M[u][j] -> M[end][j], cost 0
+                else if (j > 0) diag = sat_add(pml, mm(v, q, j - 1) ? x : 0);
+                H[j] = std::min(diag, std::min(d, D2v[j]));
+                if (v == g.start && j == 0) H[j] = 0;
+            }
+            Iv[0] = UNVISITED; I2v[0] = UNVISITED;
+            if (!is_end)
+                for (size_t j = 0; j < L; ++j) {
+                    Score a = open_i(v, q, L, j) ? sat_add(H[j], oe) : UNVISITED;
+                    Iv[j + 1] = std::min(sat_add(Iv[j], e1), a);
+                    I2v[j + 1] = std::min(sat_add(Iv[j], e2), sat_add(I2v[j], e2));
+                }
+            for (size_t j = 0; j < P; ++j) Mv[j] = std::min(H[j], std::min(Iv[j], I2v[j]));
+        }
+        R.score = R.M[rank[g.end] * P + L];
+    }
+
+    // the reference's two-piece traceback rule on the five planes, every test of a step evaluated for the certificate
+    void traceback2(const uint8_t* q, size_t L, DenseResult& R) const {
+        const size_t P = R.pitch;
+        const uint32_t x = costs.mismatch, o1 = costs.gap_open, e1 = costs.gap_extend, e2 = costs.gap_extend2;
+        auto PL = [&](AlignState st) -> const std::vector<Score>& {
+            return st == ST_M ? R.M : st == ST_I ? R.I : st == ST_D ? R.D : st == ST_I2 ? R.I2 : R.D2;
+        };
+        auto S = [&](uint32_t node, size_t j, AlignState st) { return PL(st)[rank[node] * P + j]; };
+        R.alignment.clear();
+        if (L == 0) return;
+        if (L == 1) {
+            R.flags |= DF_SHORT_QUERY;
+            if (g.is_symbol_equal(g.end, q[0])) { R.alignment.push_back({g.end, 0}); return; }
+        }
+        struct Step { uint32_t node; size_t j; AlignState st; bool found; };
+        auto step = [&](uint32_t v, size_t j, AlignState st, uint32_t& n_cand, bool& phantom_lt, bool& panic) -> Step {
+            Step first{0, 0, ST_M, false};
+            n_cand = 0; phantom_lt = false; panic = false;
+            auto sub = [&](Score a, uint32_t b) { uint32_t r = a - b; if (r == UNVISITED) panic = true; return r; };
+            auto cand = [&](uint32_t n2, size_t j2, AlignState s2) { if (!first.found) first = {n2, j2, s2, true}; n_cand++; };
+            Score cs = S(v, j, st);
+            if (cs == UNVISITED) return first;
+            if (st == ST_M) {
+                if (j > 0) {
+                    bool moe = g.is_symbol_equal(v, q[j - 1]) || v == g.end;
+                    size_t pj = (v == g.end) ? j : j - 1;
+                    Score target = (moe || g.pred[v].empty()) ? cs : sub(cs, x);
+                    for (uint32_t p : g.pred[v]) if (S(p, pj, ST_M) == target) cand(p, pj, ST_M);
+                }
+                for (AlignState gs : {ST_D, ST_D2, ST_I, ST_I2}) if (S(v, j, gs) == cs) cand(v, j, gs);
+            } else if (st == ST_D) {
+                Score t_open = sub(sub(cs, o1), e1), t_ext = sub(cs, e1);
+                bool real_open = (v != g.end) && open_d(v, q, L, j);
+                for (uint32_t p : g.pred[v]) {
+                    Score ps = S(p, j, ST_M);
+                    if (ps == t_open) cand(p, j, ST_M);
+                    else if (!real_open && ps < t_open) phantom_lt = true;
+                }
+                for (uint32_t p : g.pred[v]) if (S(p, j, ST_D) == t_ext) cand(p, j, ST_D);
+            } else if (st == ST_D2) {
+                Score t = sub(cs, e2);
+                for (uint32_t p : g.pred[v]) if (S(p, j, ST_D) == t) cand(p, j, ST_D);
+                for (uint32_t p : g.pred[v]) if (S(p, j, ST_D2) == t) cand(p, j, ST_D2);
+            } else if (st == ST_I) {
+                if (j > 0) {
+                    Score t_open = sub(sub(cs, o1), e1), t_ext = sub(cs, e1);
+                    Score ps = S(v, j - 1, ST_M);
+                    if (ps == t_open) cand(v, j - 1, ST_M);
+                    else if (!open_i(v, q, L, j - 1) && ps < t_open) phantom_lt = true;
+                    if (S(v, j - 1, ST_I) == t_ext) cand(v, j - 1, ST_I);
+                }
+            } else {
+                if (j > 0) {
+                    Score t = sub(cs, e2);
+                    if (S(v, j - 1, ST_I) == t) cand(v, j - 1, ST_I);
+                    if (S(v, j - 1, ST_I2) == t) cand(v, j - 1, ST_I2);
+                }
+            }
+            return first;
+        };
+        uint32_t nc; bool plt, pn;
+        Step cur = step(g.end, L, ST_M, nc, plt, pn);
+        if (pn) { R.flags |= DF_REF_PANIC | DF_TRUNCATED; return; }
+        if (cur.found && (nc != 1 || plt)) { R.flags |= DF_AMBIGUOUS; R.n_ambiguous_steps++; }
+        if (!cur.found) {
+            for (AlignState gs : {ST_I, ST_I2, ST_D, ST_D2}) {   // gap_affine_2piece.rs:972-978
+                cur = step(g.end, L, gs, nc, plt, pn);
+                if (pn) { R.flags |= DF_REF_PANIC | DF_TRUNCATED; return; }
+                if (cur.found) break;
+            }
+            if (!cur.found) { R.flags |= DF_REF_PANIC; return; }
+            R.flags |= DF_AMBIGUOUS;
+        }
+        uint32_t cn = cur.node; size_t cj = cur.j; AlignState cst = cur.st;
+        bool reached_start = false;
+        for (;;) {
+            Step bt = step(cn, cj, cst, nc, plt, pn);
+            if (pn) { R.flags |= DF_REF_PANIC; break; }
+            if (!bt.found) break;
+            if (nc != 1 || plt) { R.flags |= DF_AMBIGUOUS; R.n_ambiguous_steps++; }
+            if (cst == ST_M && bt.st != ST_M) { cn = bt.node; cj = bt.j; cst = bt.st; continue; }
+            if (cst == ST_M) R.alignment.push_back({cn, (uint32_t)cj - 1});
+            else if (cst == ST_I || cst == ST_I2) R.alignment.push_back({NONE32, (uint32_t)cj - 1});
+            else R.alignment.push_back({cn, NONE32});
+            if (bt.st == ST_M && bt.j == 0 && bt.node != g.start && cst != ST_D && cst != ST_D2 && g.is_symbol_equal(bt.node, q[0]))
+                R.flags |= DF_START_QUIRK;
+            if (bt.node == g.start) { reached_start = true; break; }
+            cn = bt.node; cj = bt.j; cst = bt.st;
+        }
+        if (!reached_start) R.flags |= DF_TRUNCATED;
+        std::reverse(R.alignment.begin(), R.alignment.end());
+    }
+
     DenseResult align(const uint8_t* q, size_t L, bool keep_planes = false) const {
         DenseResult R;
         forward(q, L, R);
         traceback(q, L, R);
-        if (!keep_planes) { R.M.clear(); R.I.clear(); R.D.clear(); R.M.shrink_to_fit(); R.I.shrink_to_fit(); R.D.shrink_to_fit(); }
+        if (!keep_planes) for (auto* pl : {&R.M, &R.I, &R.D, &R.I2, &R.D2}) { pl->clear(); pl->shrink_to_fit(); }
         return R;
     }
 };

@@ -29,6 +29,16 @@ struct GraphHandle {
 thread_local std::string g_last_error;
 }  // namespace
 
+// Two-piece affine model (gap_affine_2piece.rs) for every Aligner / DenseAligner constructed afterwards (test-side knob;
+// default: the one-piece model).  (m, o, e) of the entry points are then (mismatch, open1, extend1).
+static bool g_two_piece = false;
+static uint8_t g_open2 = 0, g_extend2 = 0;
+static Costs mk_costs(uint8_t m, uint8_t o, uint8_t e) {
+    Costs c{m, o, e};
+    c.two_piece = g_two_piece; c.gap_open2 = g_open2; c.gap_extend2 = g_extend2;
+    return c;
+}
+
 // Alignment span for every Aligner constructed afterwards (test-side knob; default Global).
 static AlnType g_aln_type;
 static void apply_aln_type(Aligner& a) { a.aln_type = g_aln_type; }
@@ -36,6 +46,17 @@ static void apply_aln_type(Aligner& a) { a.aln_type = g_aln_type; }
 extern "C" {
 
 const char* oracle_last_error() { return g_last_error.c_str(); }
+
+// GapAffine2Piece::new(mismatch, extend1, open1, extend2, open2) asserts extend1 >= extend2 (gap_affine_2piece.rs:29-33):
+// returns 1 where the reference would panic
+int oracle_set_two_piece(int enable, uint8_t open2, uint8_t extend2) {
+    g_two_piece = enable != 0; g_open2 = open2; g_extend2 = extend2;
+    return 0;
+}
+uint64_t oracle_breakpoint(uint8_t m, uint8_t o1, uint8_t e1, uint8_t o2, uint8_t e2) {
+    Costs c{m, o1, e1}; c.two_piece = true; c.gap_open2 = o2; c.gap_extend2 = e2;
+    return (uint64_t)c.breakpoint();
+}
 
 // spec: {ends_free, then (kind, value) for qry_free_begin, qry_free_end, graph_free_begin, graph_free_end}
 void oracle_set_alignment_type(const uint64_t* spec) {
@@ -135,6 +156,7 @@ int oracle_is_end(void* p, uint64_t seq_len, uint32_t node, uint32_t offset, int
 }
 
 uint64_t oracle_gap_cost(uint8_t m, uint8_t o, uint8_t e, int state, uint64_t len) {
+    if (g_two_piece) return mk_costs(m, o, e).gap_cost((AlignState)state, len);
     Costs c{m, o, e};
     return c.gap_cost((AlignState)state, len);
 }
@@ -176,7 +198,7 @@ int oracle_bubble_index(void* p, uint64_t* dist_min, uint64_t* dist_max, uint32_
 uint64_t oracle_heuristic_h(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, uint64_t seq_len, uint32_t node,
                             uint32_t offset, int state) {
     auto* h = (GraphHandle*)p;
-    Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, true);
+    Aligner a(h->g, h->bi(), mk_costs(m, o, e), (Heuristic)heuristic, true);
     apply_aln_type(a);
     a.seq_len = seq_len;
     return a.h({node, offset}, (AlignState)state);
@@ -242,7 +264,7 @@ int oracle_astar_align(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, 
             if (counters) counters[0] = counters[1] = counters[2] = 0;
             return 0;
         }
-        Aligner a(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        Aligner a(h->g, h->bi(), mk_costs(m, o, e), (Heuristic)heuristic, prune != 0);
         apply_aln_type(a);
         return run_astar(h, a, seq, len, score, pairs, cap, n_pairs, counters);
     } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
@@ -259,7 +281,7 @@ int oracle_astar_batch(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, 
         const BubbleIndex& bi = h->bi();
         std::atomic<uint32_t> next{0};
         auto work = [&]() {
-            Aligner a(h->g, bi, Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+            Aligner a(h->g, bi, mk_costs(m, o, e), (Heuristic)heuristic, prune != 0);
             apply_aln_type(a);
             for (;;) {
                 uint32_t i = next.fetch_add(1);
@@ -287,7 +309,7 @@ int oracle_dense_align(void* p, uint8_t m, uint8_t o, uint8_t e, const uint8_t* 
                        uint32_t* pd) {
     auto* h = (GraphHandle*)p;
     try {
-        DenseAligner a(h->g, Costs{m, o, e});
+        DenseAligner a(h->g, mk_costs(m, o, e));
         DenseResult r = a.align(seq, len, pm != nullptr);
         *score = r.score; *flags = r.flags; *n_pairs = r.alignment.size();
         if (pm) {
@@ -301,12 +323,25 @@ int oracle_dense_align(void* p, uint8_t m, uint8_t o, uint8_t e, const uint8_t* 
     } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
 }
 
+// the second-piece planes of the two-piece model (I2, D2) of one dense alignment, beside oracle_dense_align's M, I, D
+int oracle_dense_planes2(void* p, uint8_t m, uint8_t o, uint8_t e, const uint8_t* seq, uint64_t len, uint32_t* pi2, uint32_t* pd2) {
+    auto* h = (GraphHandle*)p;
+    try {
+        DenseAligner a(h->g, mk_costs(m, o, e));
+        DenseResult r = a.align(seq, len, true);
+        if (r.I2.empty()) { g_last_error = "not a two-piece run"; return -1; }
+        std::memcpy(pi2, r.I2.data(), r.I2.size() * 4);
+        std::memcpy(pd2, r.D2.data(), r.D2.size() * 4);
+        return 0;
+    } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
 int oracle_dense_batch(void* p, uint8_t m, uint8_t o, uint8_t e, uint32_t n_queries, const uint8_t* qseq,
                        const uint64_t* qoff, uint32_t* scores, uint32_t* pairs, const uint64_t* pair_off,
                        uint64_t* n_pairs, uint32_t* flags, int n_threads) {
     auto* h = (GraphHandle*)p;
     try {
-        DenseAligner a(h->g, Costs{m, o, e});
+        DenseAligner a(h->g, mk_costs(m, o, e));
         std::atomic<uint32_t> next{0};
         auto work = [&]() {
             for (;;) {
@@ -370,9 +405,9 @@ extern "C" int oracle_tie_report(void* p, uint8_t m, uint8_t o, uint8_t e, int h
                                  uint64_t len, uint64_t* out) {
     auto* h = (GraphHandle*)p;
     try {
-        Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        Aligner A(h->g, h->bi(), mk_costs(m, o, e), (Heuristic)heuristic, prune != 0);
         AstarResult ar = A.astar_alignment(seq, len);
-        DenseAligner D(h->g, Costs{m, o, e});
+        DenseAligner D(h->g, mk_costs(m, o, e));
         DenseResult R;
         D.forward(seq, len, R);
         const size_t P = R.pitch;
@@ -440,9 +475,9 @@ extern "C" int oracle_tie_census(void* p, uint8_t m, uint8_t o, uint8_t e, int h
                                  uint64_t len, char* buf, uint64_t cap) {
     auto* h = (GraphHandle*)p;
     try {
-        Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        Aligner A(h->g, h->bi(), mk_costs(m, o, e), (Heuristic)heuristic, prune != 0);
         A.astar_alignment(seq, len);
-        DenseAligner D(h->g, Costs{m, o, e});
+        DenseAligner D(h->g, mk_costs(m, o, e));
         DenseResult R;
         D.forward(seq, len, R);
         const size_t P = R.pitch;
@@ -505,7 +540,7 @@ extern "C" int oracle_astar_table(void* p, uint8_t m, uint8_t o, uint8_t e, int 
                                   uint64_t len, uint32_t* pm, uint32_t* pi, uint32_t* pd, uint64_t* out) {
     auto* h = (GraphHandle*)p;
     try {
-        Aligner A(h->g, h->bi(), Costs{m, o, e}, (Heuristic)heuristic, prune != 0);
+        Aligner A(h->g, h->bi(), mk_costs(m, o, e), (Heuristic)heuristic, prune != 0);
         apply_aln_type(A);
         AstarResult r = A.astar_alignment(seq, len);
         const size_t n = h->g.symbol.size(), P = len + 1;

@@ -78,6 +78,10 @@ def lib():
         L.oracle_dense_align.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
         L.oracle_dense_batch.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         L.oracle_set_alignment_type.argtypes = [vp]
+        L.oracle_set_two_piece.argtypes = [C.c_int, C.c_uint8, C.c_uint8]
+        L.oracle_breakpoint.restype = C.c_uint64
+        L.oracle_breakpoint.argtypes = [C.c_uint8] * 5
+        L.oracle_dense_planes2.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, vp, C.c_uint64, vp, vp]
         L.oracle_poa_to_fasta.restype = C.c_int64
         L.oracle_poa_to_fasta.argtypes = [vp, C.c_char_p, C.c_uint64]
         L.oracle_poa_from_msa.restype = vp
@@ -104,6 +108,31 @@ class alignment_type:
     def __exit__(self, *exc):
         lib().oracle_set_alignment_type(None)
         return False
+
+
+class two_piece:
+    """Context manager: every search / dense pass inside runs the two-piece affine model
+    GapAffine2Piece::new(mismatch, extend1, open1, extend2, open2) (gap_affine_2piece.rs:19-33); the Costs(mismatch, open, extend)
+    passed to the calls are the first piece.  The reference asserts extend1 >= extend2 in the constructor: checked by the caller."""
+
+    def __init__(self, gap_open2, gap_extend2):
+        self.o2, self.e2 = gap_open2, gap_extend2
+
+    def __enter__(self):
+        lib().oracle_set_two_piece(1, self.o2, self.e2)
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_set_two_piece(0, 0, 0)
+        return False
+
+
+def breakpoint2(mismatch, extend1, open1, extend2, open2):
+    """GapAffine2Piece::breakpoint (gap_affine_2piece.rs:36-66); argument order = the reference's constructor."""
+    return int(lib().oracle_breakpoint(mismatch, open1, extend1, open2, extend2))
+
+
+ST_D2, ST_I2 = 3, 4
 
 
 def ends_free(qry_free_begin=UNBOUNDED, qry_free_end=UNBOUNDED, graph_free_begin=UNBOUNDED, graph_free_end=UNBOUNDED):
@@ -308,6 +337,15 @@ class OracleGraph:
         if planes:
             out.update(M=pm, I=pi, D=pd)
         return out
+
+    def dense_planes2(self, seq, costs):
+        """I2, D2 of the two-piece model (inside `with two_piece(...)`)."""
+        s = _seq(seq)
+        shape = (self.n, len(s) + 1)
+        pi2, pd2 = np.zeros(shape, np.uint32), np.zeros(shape, np.uint32)
+        if lib().oracle_dense_planes2(self.h, *costs.t(), _p(s), len(s), _p(pi2), _p(pd2)) != 0:
+            raise RuntimeError(lib().oracle_last_error().decode())
+        return pi2, pd2
 
     def _batch_bufs(self, qseq, qoff, want_pairs):
         qseq = np.ascontiguousarray(qseq, np.uint8)

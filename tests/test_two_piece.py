@@ -1,0 +1,130 @@
+"""Two-piece affine model (/root/reference/src/aligner/scoring/gap_affine_2piece.rs).
+
+CPU: the oracle's restatement against every known answer the reference's own tests hold (gap_affine_2piece.rs:1179-1420:
+breakpoints, gap_cost values, score relations between the one-piece and the two-piece model on the reference's own little
+graphs), and the dense five-plane restatement (the kernels' executable specification) against the restated search.
+GPU: the five-plane kernel through the C ABI against the dense restatement, plane by plane, and against the search.
+Alignments of the two-piece model are "parity unpinned" like the one-piece ones: the reference asserts scores only."""
+import numpy as np
+import pytest
+
+from poasta_amd import workloads as W
+from poasta_amd.graph import pack_queries
+
+
+def _simple(oracle, seq="ACGT"):
+    g = oracle.OracleGraph.new_poa()
+    g.add_alignment("seq1", seq)
+    return g
+
+
+def _bubble(oracle):
+    g = oracle.OracleGraph.new_poa()   # two unaligned sequences: two parallel paths (gap_affine_2piece.rs:1162-1177)
+    g.add_alignment("seq1", "ATGC")
+    g.add_alignment("seq2", "AAAC")
+    return g
+
+
+def _a1(oracle, g, q, m, e, o):
+    return g.astar_align(q, oracle.Costs(m, o, e), oracle.H_DIJKSTRA, True)
+
+
+def _a2(oracle, g, q, m, e1, o1, e2, o2, heur=None, prune=True):
+    """GapAffine2Piece::new(m, e1, o1, e2, o2): the reference's argument order."""
+    with oracle.two_piece(o2, e2):
+        return g.astar_align(q, oracle.Costs(m, o1, e1), oracle.H_DIJKSTRA if heur is None else heur, prune)
+
+
+def test_breakpoint_and_gap_cost_kats(oracle):
+    # gap_affine_2piece.rs:1179-1210
+    assert oracle.breakpoint2(1, 2, 10, 1, 8) == 2
+    assert oracle.breakpoint2(1, 4, 12, 1, 9) == 1
+    assert oracle.breakpoint2(1, 3, 11, 1, 5) == 3
+    c = oracle.Costs(1, 10, 2)
+    with oracle.two_piece(8, 1):
+        assert [oracle.gap_cost(c, oracle.ST_M, k) for k in (0, 1, 2, 3)] == [0, 9, 10, 11]
+        assert oracle.gap_cost(c, oracle.ST_I, 1) == 12 and oracle.gap_cost(c, oracle.ST_D, 2) == 14
+        assert oracle.gap_cost(c, oracle.ST_I2, 1) == 9 and oracle.gap_cost(c, oracle.ST_D2, 2) == 10
+
+
+def test_score_relations_of_the_reference_tests(oracle):
+    g = _simple(oracle)
+    # :1213-1231 equal scores on a perfect match
+    assert _a1(oracle, g, "ACGT", 1, 1, 5)["score"] == _a2(oracle, g, "ACGT", 1, 2, 5, 1, 5)["score"] == 0
+    # :1235-1259 a long insertion is cheaper in the two-piece model
+    assert _a2(oracle, g, "ACCCCCCGT", 1, 2, 10, 1, 8)["score"] < _a1(oracle, g, "ACCCCCCGT", 1, 2, 10)["score"]
+    # :1262-1283 two parallel paths, same score
+    b = _bubble(oracle)
+    assert _a1(oracle, b, "ACGT", 2, 1, 4)["score"] == _a2(oracle, b, "ACGT", 2, 2, 6, 1, 3)["score"]
+    # :1286-1304 deletion: lower or equal;  SURVEY appendix C: ACGT x AC under (1, 10, 2) is 14
+    assert _a1(oracle, g, "AC", 1, 2, 10)["score"] == 14
+    assert _a2(oracle, g, "AC", 1, 2, 10, 1, 8)["score"] <= 14
+    # :1308-1326 different parameters, different scores
+    assert _a2(oracle, b, "ATTTAAC", 3, 3, 12, 1, 6)["score"] != _a2(oracle, b, "ATTTAAC", 3, 4, 15, 1, 5)["score"]
+    # :1329-1344 a non-empty alignment with a positive score
+    r = _a2(oracle, g, "ACTTTGT", 1, 3, 10, 1, 7)
+    assert r["alignment"] and r["score"] > 0
+    # :1353-1381 twelve inserted bases: more than 10 cheaper;  :1384-1420 six inserted bases: cheaper
+    g8 = _simple(oracle, "ACGTACGT")
+    s1, s2 = _a1(oracle, g8, "ACGTTTTTTTTTTTTTACGT", 1, 3, 15)["score"], _a2(oracle, g8, "ACGTTTTTTTTTTTTTACGT", 1, 3, 15, 1, 5)["score"]
+    assert s2 < s1 and s1 - s2 > 10
+    assert _a2(oracle, g8, "ACGTTTTTTTACGT", 1, 3, 12, 1, 6)["score"] < _a1(oracle, g8, "ACGTTTTTTTACGT", 1, 3, 12)["score"]
+    # a gap of k costs open1 + extend1 + (k - 1) * extend2 (open2 is never charged, gap_affine_2piece.rs:362-368): 6 T's -> 12 + 3 + 5.
+    # That optimum is what the search returns in Dijkstra order WITHOUT pruning.  Restated literally, pruning (23) and the
+    # min-gap heuristic (38: gap_cost charges open1 again for a state that already is inside a gap, :112-115, so h
+    # over-estimates) leave it — found while testing, no reference fixture covers it ("parity unpinned").
+    assert _a2(oracle, g8, "ACGTTTTTTTACGT", 1, 3, 12, 1, 6, prune=False)["score"] == 20
+    assert _a2(oracle, g8, "ACGTTTTTTTACGT", 1, 3, 12, 1, 6, prune=True)["score"] == 23
+    assert _a2(oracle, g8, "ACGTTTTTTTACGT", 1, 3, 12, 1, 6, heur=oracle.H_MINGAP, prune=False)["score"] == 38
+
+
+COSTS2 = [(4, 2, 6, 1, 24), (1, 2, 10, 1, 8), (3, 3, 12, 1, 6), (2, 2, 4, 2, 4), (4, 3, 5, 0, 9)]   # (m, e1, o1, e2, o2)
+
+
+def test_dense_five_planes_equal_the_search(oracle):
+    """Dense restatement of the two-piece alignment graph (oracle/dense.hpp forward2 / traceback2) against the restated search
+    in Dijkstra order with pruning off.  The dense pass is the optimum of the search's own edge set, so it is never above
+    the search; it is BELOW it now and then, because the greedy extension prunes whatever `enable_pruning` says
+    (dfa.rs:185) and the two-piece gap_cost that pruning reasons with (min(open1 + k*ext1, open2 + k*ext2),
+    gap_affine_2piece.rs:120-125) undercuts what a gap really costs here (open1 + ext1 + (k-1)*ext2): e.g. seed 6,
+    GGTCCG, costs (1, 2, 10, 1, 8): search 14, optimum 13.  Where the scores agree and the dense pass certifies its
+    alignment (flags == 0), the alignments agree."""
+    n = n_cert = n_below = 0
+    for seed in range(60):
+        rng = np.random.Generator(np.random.PCG64(7000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        og = oracle.OracleGraph.from_csr(g.as_dict())
+        m, e1, o1, e2, o2 = COSTS2[seed % len(COSTS2)]
+        for _ in range(6):
+            q = W.random_walk_query(rng, g, 0.35, alpha)
+            if len(q) < 2:
+                continue
+            with oracle.two_piece(o2, e2):
+                try:
+                    a = og.astar_align(q, oracle.Costs(m, o1, e1), oracle.H_DIJKSTRA, False)
+                except oracle.RefPanic:
+                    continue
+                d = og.dense_align(q, oracle.Costs(m, o1, e1))
+            if d["flags"] & (oracle.DF_START_QUIRK | oracle.DF_SHORT_QUERY | oracle.DF_REF_PANIC):
+                continue
+            assert d["score"] <= a["score"], (seed, bytes(q))
+            n += 1
+            if d["score"] < a["score"]:
+                n_below += 1
+            elif d["flags"] == 0:
+                assert d["alignment"] == a["alignment"], (seed, bytes(q))
+                n_cert += 1
+    assert n > 250 and n_cert > 40 and n_below < n // 10
+    # the one-piece model is the special case extend2 == extend1 (the second piece is never cheaper): same scores
+    for seed in range(12):
+        rng = np.random.Generator(np.random.PCG64(7100 + seed))
+        g = W.random_dag(seed, n_nodes=10, p_edge=0.3)
+        og = oracle.OracleGraph.from_csr(g.as_dict())
+        q = W.random_walk_query(rng, g, 0.3)
+        if len(q) < 2:
+            continue
+        one = og.dense_align(q, oracle.Costs(4, 6, 2))
+        with oracle.two_piece(6, 2):
+            two = og.dense_align(q, oracle.Costs(4, 6, 2))
+        assert one["score"] == two["score"]
