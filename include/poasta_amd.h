@@ -65,6 +65,19 @@ typedef struct poa_costs {
     uint8_t reserved;
 } poa_costs_t;
 
+/* GapAffine2Piece (src/aligner/scoring/gap_affine_2piece.rs:19-33; the reference's constructor order is (mismatch, extend1,
+ * open1, extend2, open2) and it asserts extend1 >= extend2).  A gap opens in the first piece (open1 + extend1) and may move to
+ * the second at extend2 per step; open2 enters only the reference's heuristic / pruning arithmetic, never the DP
+ * (gap_affine_2piece.rs:362-368, :402-408), so the dense pass does not read it. */
+typedef struct poa_costs2 {
+    uint8_t mismatch;
+    uint8_t gap_open1;
+    uint8_t gap_extend1;
+    uint8_t gap_open2;
+    uint8_t gap_extend2;
+    uint8_t reserved[3];
+} poa_costs2_t;
+
 /* Which reference configuration the exact replay emulates (only the replay depends on it: heuristic and pruning
  * fix the reference's search order, not its optimum).  Zero-initialised == dense mode. */
 /* std::ops::Bound<usize> of AlignmentType::EndsFree (scoring/mod.rs:50-62) */
@@ -168,6 +181,21 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
                        const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
                        poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
                        uint32_t* flags, poa_stats_t* stats, int device);
+/* Two-piece affine model, Global, dense pass: replaces `PoastaAligner::new(Affine2PieceDijkstra(costs),
+ * AlignmentType::Global).align_no_pruning(graph, seq)` per query — src/aligner/config.rs:160-213, the cost model of
+ * `poasta align -g 6,24 -e 2,1` (src/bin/poasta.rs:319-445).  Same buffers as poa_align_batch.  Scores are the optimum of the
+ * reference's two-piece alignment graph (what its search returns in Dijkstra order without pruning); flags == 0 certifies
+ * the alignment as the one the reference's backtrace rule forces (gap_affine_2piece.rs:639-794).  Returns
+ * POA_ERR_INVALID_ARG where the reference's constructor panics (extend1 < extend2). */
+int poa_align_batch_2piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_queries,
+                           const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
+                           poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
+                           uint32_t* flags, poa_stats_t* stats, int device);
+/* debugging / parity: the five score planes M, I1, D1, I2, D2 of ONE query, rows x (len + 1) each, row = topological rank
+ * (poa_graph_node_rows) */
+int poa_planes_2piece(const poa_graph_t* g, const poa_costs2_t* costs, const uint8_t* seq, uint32_t len,
+                      uint32_t* m, uint32_t* i1, uint32_t* d1, uint32_t* i2, uint32_t* d2, int device);
+
 /* poa_align_batch parks its plane workspace (tens of GB; hipMalloc/hipFree of it cost seconds) per device for the next
  * call; this returns that memory to the driver.  (src/bin/lasagna.rs has no counterpart: its tables live on the heap.) */
 void poa_release_cache(void);

@@ -48,6 +48,54 @@ class GapAffine:
         return _lib.PoaCosts(self.cost_mismatch, self.cost_gap_open, self.cost_gap_extend, 0)
 
 
+class GapAffine2Piece:
+    """`GapAffine2Piece::new(cost_mismatch, cost_gap_extend1, cost_gap_open1, cost_gap_extend2, cost_gap_open2)` — the
+    reference's argument order (gap_affine_2piece.rs:28-33); it panics unless extend1 >= extend2."""
+
+    def __init__(self, cost_mismatch, cost_gap_extend1, cost_gap_open1, cost_gap_extend2, cost_gap_open2):
+        if cost_gap_extend1 < cost_gap_extend2:
+            raise ValueError("gap_extend1 must be greater than or equal to gap_extend2 for two-piece model")
+        self.cost_mismatch, self.cost_gap_extend1, self.cost_gap_open1 = cost_mismatch, cost_gap_extend1, cost_gap_open1
+        self.cost_gap_extend2, self.cost_gap_open2 = cost_gap_extend2, cost_gap_open2
+
+    def mismatch(self):
+        return self.cost_mismatch
+
+    def gap_open(self):
+        return self.cost_gap_open1
+
+    def gap_extend(self):
+        return self.cost_gap_extend1
+
+    def gap_open2(self):
+        return self.cost_gap_open2
+
+    def gap_extend2(self):
+        return self.cost_gap_extend2
+
+    def breakpoint(self):
+        """gap_affine_2piece.rs:36-66"""
+        if self.cost_gap_extend1 == self.cost_gap_extend2:
+            return (1 << 64) - 1 if self.cost_gap_open1 <= self.cost_gap_open2 else 0
+        den = self.cost_gap_extend1 - self.cost_gap_extend2
+        if self.cost_gap_open2 >= self.cost_gap_open1:
+            return (self.cost_gap_open2 - self.cost_gap_open1) // den
+        return (self.cost_gap_open1 - self.cost_gap_open2 + den - 1) // den
+
+    def _c(self):
+        return _lib.PoaCosts2(self.cost_mismatch, self.cost_gap_open1, self.cost_gap_extend1, self.cost_gap_open2, self.cost_gap_extend2)
+
+
+class Affine2PieceDijkstra:
+    """config.rs:160-213.  The engine's two-piece pass is the dense one (Global): the optimum of the reference's two-piece
+    alignment graph = what this configuration's search returns without pruning (`align_no_pruning`)."""
+    heuristic = _lib.HEURISTIC_DIJKSTRA
+    two_piece = True
+
+    def __init__(self, costs):
+        self.costs = costs
+
+
 class Bound:
     """std::ops::Bound<usize> as the reference's AlignmentType::EndsFree uses it."""
     Unbounded = (_lib.BOUND_UNBOUNDED, 0)
@@ -294,6 +342,16 @@ class PoastaAligner:
         """mod.rs:81-90 (matters only for the exact replay: no pruning changes which cells the reference visits)."""
         return self.align(ref_graph, seq, pruning=False)
 
+    def planes_2piece(self, ref_graph, seq):
+        """M, I1, D1, I2, D2 of one query under the two-piece model, rows = topological rank (parity tests)."""
+        dg = _device_graph(ref_graph)
+        s = np.ascontiguousarray(np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else seq, np.uint8)
+        shape = (dg.graph.n, len(s) + 1)
+        out = [np.zeros(shape, np.uint32) for _ in range(5)]
+        c = self.config.costs._c()
+        _lib.check(_lib.lib().poa_planes_2piece(dg.handle, C.byref(c), _p(s), len(s), *[_p(a) for a in out], self.device))
+        return out
+
     # -- batch shape (lasagna.rs:246-268) ------------------------------------------------------
     def align_batch(self, ref_graph, seqs=None, qseq=None, qoff=None, want_pairs=True, pruning=True):
         dg = _device_graph(ref_graph)
@@ -308,6 +366,14 @@ class PoastaAligner:
         pairs = np.zeros((max(cap, 1), 2), np.uint32) if want_pairs else None
         st = _lib.PoaStats()
         c = self.config.costs._c()
+        if getattr(self.config, "two_piece", False):
+            if self.aln_type != AlignmentType.Global or self.mode != "dense":
+                raise ValueError("the two-piece model runs as the dense Global pass")
+            _lib.check(_lib.lib().poa_align_batch_2piece(dg.handle, C.byref(c), n, _p(qseq), _p(qoff), _p(score), _p(pairs),
+                                                         _p(pair_off), cap, _p(flags), C.byref(st), self.device))
+            if want_pairs:
+                pairs = pairs[:int(pair_off[n])]
+            return BatchResult(score, pairs, pair_off, flags, st.as_dict())
         cfg = make_config(self.mode, self.config.heuristic, pruning, self.queue_entries_per_cell, aln_type=self.aln_type)
         _lib.check(_lib.lib().poa_align_batch_ex(dg.handle, C.byref(c), C.byref(cfg), n, _p(qseq), _p(qoff), _p(score),
                                                  _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), self.device))

@@ -23,6 +23,7 @@
 #include "poa_kernels.hpp"
 #include "poa_forward_packed.hpp"
 #include "poa_forward_px.hpp"
+#include "poa_twopiece.hpp"
 
 using namespace poa_amd;
 
@@ -1028,3 +1029,133 @@ void poa_release_cache(void) {
 }
 
 }  // extern "C"
+
+
+// ---- two-piece affine model (poa_twopiece.hpp) ---------------------------------------------------------------------------
+namespace {
+// planes_out: null, or five host pointers (M, I1, D1, I2, D2) receiving the planes of query 0, rows x (len + 1)
+int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_queries, const uint8_t* qseq, const uint64_t* qoff,
+                  uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity, uint32_t* flags,
+                  poa_stats_t* stats, int device, uint32_t* const* planes_out) {
+    if (!g || !costs || (n_queries && (!qseq || !qoff))) return fail(POA_ERR_INVALID_ARG, "poa_align_batch_2piece: null argument");
+    if (costs->gap_extend1 < costs->gap_extend2)
+        return fail(POA_ERR_INVALID_ARG, "gap_extend1 must be greater than or equal to gap_extend2 for two-piece model");
+    if (poa_device_count() <= 0) return fail(POA_ERR_NO_DEVICE, "no HIP device: the engine has no CPU alignment path");
+    HIP_TRY(hipSetDevice(device));
+    const FlatGraph& fg = g->g;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (pair_off) pair_off[0] = 0;
+    if (n_queries == 0) return POA_OK;
+    uint64_t max_len = 0, cells = 0;
+    for (uint32_t i = 0; i < n_queries; ++i) {
+        if (qoff[i + 1] < qoff[i]) return fail(POA_ERR_INVALID_ARG, "qoff must be non-decreasing");
+        max_len = std::max<uint64_t>(max_len, qoff[i + 1] - qoff[i]);
+        cells += (uint64_t)fg.n * (qoff[i + 1] - qoff[i] + 1);
+    }
+    if (fg.n_real == 0) {  // empty graph: mod.rs:124-142
+        for (uint32_t i = 0; i < n_queries; ++i) {
+            if (score) score[i] = (uint32_t)(4 * (qoff[i + 1] - qoff[i]));
+            if (flags) flags[i] = 0;
+            if (pair_off) pair_off[i + 1] = 0;
+        }
+        return POA_OK;
+    }
+    const uint32_t pitch = (uint32_t)((max_len + 64) & ~63ull);
+    const uint64_t per_query = 5ull * fg.n * pitch;   // u32 elements
+    if (per_query >= (1ull << 34)) return fail(POA_ERR_UNSUPPORTED, "two-piece pass: planes of one query too large");
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::min<uint64_t>((uint64_t)(free_b * 0.6), 64ull << 30);
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_queries, budget / (per_query * 4 + 1)));
+    const uint32_t stride = (uint32_t)std::min<uint64_t>(fg.n + max_len + 1, 0xFFFFFFFFull);
+    DevBuf<RowMeta> d_rows; DevBuf<uint32_t> d_pred, d_planes, d_score, d_flags, d_np; DevBuf<uint8_t> d_q; DevBuf<uint64_t> d_qoff;
+    DevBuf<poa_aln_pair_t> d_scratch;
+    HIP_TRY(d_rows.alloc(fg.rows.size())); HIP_TRY(d_pred.alloc(std::max<size_t>(fg.pred_rows.size(), 1)));
+    HIP_TRY(d_q.alloc(std::max<uint64_t>(qoff[n_queries], 1))); HIP_TRY(d_qoff.alloc(n_queries + 1));
+    HIP_TRY(d_score.alloc(n_queries)); HIP_TRY(d_flags.alloc(n_queries)); HIP_TRY(d_np.alloc(n_queries));
+    if (d_planes.alloc((size_t)chunk * per_query) != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, "two-piece pass: plane workspace");
+    HIP_TRY(d_scratch.alloc((size_t)chunk * stride));
+    HIP_TRY(hipMemcpy(d_rows.p, fg.rows.data(), fg.rows.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
+    if (!fg.pred_rows.empty()) HIP_TRY(hipMemcpy(d_pred.p, fg.pred_rows.data(), fg.pred_rows.size() * 4, hipMemcpyHostToDevice));
+    if (qoff[n_queries]) HIP_TRY(hipMemcpy(d_q.p, qseq, qoff[n_queries], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_qoff.p, qoff, ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
+    TwoPieceParams P;
+    P.rows = d_rows.p; P.pred_rows = d_pred.p; P.n_rows = fg.n; P.start_row = fg.start_row; P.end_row = fg.end_row;
+    P.qseq = d_q.p; P.qoff = d_qoff.p; P.pitch = pitch; P.planes = d_planes.p;
+    P.x = costs->mismatch; P.o1 = costs->gap_open1; P.e1 = costs->gap_extend1; P.e2 = costs->gap_extend2; P.oe = (uint32_t)costs->gap_open1 + costs->gap_extend1;
+    P.score = d_score.p; P.flags = d_flags.p; P.n_pairs = d_np.p; P.scratch = d_scratch.p; P.scratch_stride = stride;
+    hipEvent_t e0, e1, e2;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    float ms_f = 0.f, ms_t = 0.f;
+    std::vector<uint32_t> h_np(n_queries), h_flags(n_queries);
+    std::vector<poa_aln_pair_t> h_scratch((size_t)chunk * stride);
+    uint64_t at = 0;
+    uint32_t n_chunks = 0;
+    int rc = POA_OK;
+    for (uint32_t first = 0; first < n_queries; first += chunk) {
+        const uint32_t cnt = std::min(chunk, n_queries - first);
+        P.first_query = first; P.n_queries = cnt;
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(poa2_forward_kernel, dim3(cnt), dim3(64), 0, nullptr, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        hipLaunchKernelGGL(poa2_traceback_kernel, dim3((cnt + 63) / 64), dim3(64), 0, nullptr, P);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e2, nullptr));
+        HIP_TRY(hipEventSynchronize(e2));
+        float a = 0, b2 = 0;
+        (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b2, e1, e2);
+        ms_f += a; ms_t += b2; n_chunks++;
+        HIP_TRY(hipMemcpy(h_np.data() + first, d_np.p + first, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (pairs || pair_off) {
+            HIP_TRY(hipMemcpy(h_scratch.data(), d_scratch.p, (size_t)cnt * stride * sizeof(poa_aln_pair_t), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint32_t np = h_np[first + i];
+                if (np > stride) return fail(POA_ERR_HIP, "two-piece traceback: walk longer than rows + length");
+                if (pairs) {
+                    if (at + np > pair_capacity) rc = fail(POA_ERR_CAPACITY, "pair_capacity too small");
+                    else std::memcpy(pairs + at, h_scratch.data() + (size_t)i * stride + (stride - np), (size_t)np * sizeof(poa_aln_pair_t));
+                }
+                at += np;
+                if (pair_off) pair_off[first + i + 1] = at;
+            }
+        }
+        if (planes_out && first == 0) {
+            const uint32_t L0 = (uint32_t)(qoff[1] - qoff[0]);
+            std::vector<uint32_t> row(pitch);
+            for (int pl = 0; pl < 5; ++pl)
+                for (uint32_t r = 0; r < fg.n; ++r) {
+                    HIP_TRY(hipMemcpy(row.data(), d_planes.p + ((uint64_t)pl * fg.n + r) * pitch, (size_t)pitch * 4, hipMemcpyDeviceToHost));
+                    std::memcpy(planes_out[pl] + (size_t)r * (L0 + 1), row.data(), ((size_t)L0 + 1) * 4);
+                }
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    if (score) HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_flags.data(), d_flags.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+    if (flags) std::memcpy(flags, h_flags.data(), (size_t)n_queries * 4);
+    if (stats) {
+        stats->cells = cells; stats->bases = qoff[n_queries]; stats->plane_bytes = cells * 20; stats->n_queries = n_queries;
+        stats->n_chunks = n_chunks; stats->n_forward_launches = n_chunks; stats->ms_forward = ms_f; stats->ms_traceback = ms_t;
+        uint32_t nf = 0;
+        for (uint32_t i = 0; i < n_queries; ++i) nf += h_flags[i] != 0;
+        stats->n_flagged = nf;
+    }
+    return rc;
+}
+}  // namespace
+
+int poa_align_batch_2piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_queries, const uint8_t* qseq,
+                           const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
+                           uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, int device) {
+    return run_two_piece(g, costs, n_queries, qseq, qoff, score, pairs, pair_off, pair_capacity, flags, stats, device, nullptr);
+}
+
+int poa_planes_2piece(const poa_graph_t* g, const poa_costs2_t* costs, const uint8_t* seq, uint32_t len, uint32_t* m,
+                      uint32_t* i1, uint32_t* d1, uint32_t* i2, uint32_t* d2, int device) {
+    if (!m || !i1 || !d1 || !i2 || !d2) return fail(POA_ERR_INVALID_ARG, "poa_planes_2piece: null plane");
+    const uint64_t qoff[2] = {0, len};
+    uint32_t* out[5] = {m, i1, d1, i2, d2};
+    uint32_t sc = 0, fl = 0;
+    return run_two_piece(g, costs, 1, seq, qoff, &sc, nullptr, nullptr, 0, &fl, nullptr, device, out);
+}

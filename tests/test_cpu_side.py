@@ -172,7 +172,7 @@ def test_msa_import_rule():
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "poasta_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(poa_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(poa_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_abi_exports_every_declared_symbol():

@@ -128,3 +128,73 @@ def test_dense_five_planes_equal_the_search(oracle):
         with oracle.two_piece(6, 2):
             two = og.dense_align(q, oracle.Costs(4, 6, 2))
         assert one["score"] == two["score"]
+
+
+# ------------------------------------------------------------------------------------------------
+def _oracle_planes_by_row(oracle, engine, og, g, q, costs):
+    """oracle planes are [node-rank of the ORACLE's order]; re-index both sides by node."""
+    m, e1, o1, e2, o2 = costs
+    with oracle.two_piece(o2, e2):
+        d = og.dense_align(q, oracle.Costs(m, o1, e1), planes=True)
+        i2, d2 = og.dense_planes2(q, oracle.Costs(m, o1, e1))
+    orank = og.export_csr()["rank"]
+    by_node = lambda pl: pl[orank]   # row of node v = pl[rank[v]]
+    return d, [by_node(d["M"]), by_node(d["I"]), by_node(d["D"]), by_node(i2), by_node(d2)]
+
+
+@pytest.mark.gpu
+def test_gpu_two_piece_planes_scores_alignments(engine, oracle):
+    """Five-plane kernel through the C ABI: planes cell for cell, scores, flags and alignments equal the dense restatement
+    (oracle/dense.hpp forward2 / traceback2); certified alignments (flags == 0) with the search's score equal the search's."""
+    n = n_cert = 0
+    for seed in range(40):
+        rng = np.random.Generator(np.random.PCG64(7000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        og = oracle.OracleGraph.from_csr(g.as_dict())
+        costs = COSTS2[seed % len(COSTS2)]
+        m, e1, o1, e2, o2 = costs
+        al = engine.PoastaAligner(engine.Affine2PieceDijkstra(engine.GapAffine2Piece(m, e1, o1, e2, o2)))
+        qs = [q for q in (W.random_walk_query(rng, g, 0.35, alpha) for _ in range(8)) if len(q) >= 1]
+        res = al.align_batch(g, qs)
+        rows = engine._device_graph(g).node_rows()
+        for i, q in enumerate(qs):
+            d, oplanes = _oracle_planes_by_row(oracle, engine, og, g, q, costs)
+            assert int(res.score[i]) == d["score"], (seed, bytes(q))
+            assert int(res.flags[i]) == d["flags"], (seed, bytes(q))
+            assert res.raw_alignment(i) == d["alignment"], (seed, bytes(q))
+            if i < 2:
+                gp = al.planes_2piece(g, q)
+                for name, a, b in zip(("M", "I1", "D1", "I2", "D2"), gp, oplanes):
+                    assert np.array_equal(a[rows], b), (seed, bytes(q), name)
+            n += 1
+            if d["flags"] == 0 and len(q) >= 2:
+                with oracle.two_piece(o2, e2):
+                    try:
+                        a = og.astar_align(q, oracle.Costs(m, o1, e1), oracle.H_DIJKSTRA, False)
+                    except oracle.RefPanic:
+                        continue
+                if a["score"] == d["score"]:
+                    assert res.raw_alignment(i) == a["alignment"], (seed, bytes(q))
+                    n_cert += 1
+    assert n > 250 and n_cert > 30
+    with pytest.raises(ValueError):
+        engine.GapAffine2Piece(1, 1, 10, 2, 8)   # gap_affine_2piece.rs:1346-1351: extend1 < extend2 panics
+
+
+@pytest.mark.gpu
+def test_gpu_two_piece_config2_sample(engine, oracle):
+    """configs[1] shape under the CLI's two-piece example costs (-g 6,24 -e 2,1): scores and alignments equal the dense
+    restatement on a sample; chunks of the workspace are exercised by the batch size."""
+    g, (qseq, qoff) = W.config2(n_queries=48)
+    al = engine.PoastaAligner(engine.Affine2PieceDijkstra(engine.GapAffine2Piece(4, 2, 6, 1, 24)))
+    res = al.align_batch(g, qseq=qseq, qoff=qoff)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    with oracle.two_piece(24, 1):
+        D = og.dense_batch(qseq, qoff, oracle.Costs(4, 6, 2), threads=8)
+    assert np.array_equal(res.score, D["score"]) and np.array_equal(res.flags, D["flags"])
+    for i in range(48):
+        assert res.raw_alignment(i) == oracle.batch_alignment(D, i)
+    # the one-piece model with open' = o1 + e1 - e2, extend' = e2 has the same optimum (a gap of k costs o1 + e1 + (k-1) e2)
+    one = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 1, 7))).align_batch(g, qseq=qseq, qoff=qoff)
+    assert np.array_equal(one.score, res.score)
