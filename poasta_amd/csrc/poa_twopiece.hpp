@@ -1,7 +1,7 @@
 // Two-piece affine model (/root/reference/src/aligner/scoring/gap_affine_2piece.rs): the dense pass.
 // Included by poa_engine.hip (uses its poa_graph, DevBuf, HIP_TRY, fail).
 //
-// Edge set (gap_affine_2piece.rs:292-516; oracle/dense.hpp forward2 is the executable specification): a gap opens in the
+// Edge set (gap_affine_2piece.rs:292-516; the tests hold a CPU restatement as the executable specification): a gap opens in the
 // first piece exactly as in the one-piece model (open1 + extend1, greedy-match rule), every further step stays in its
 // piece or moves from the first to the second at extend2; open2 is never charged.  Five planes per query:
 //
@@ -118,8 +118,7 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
 }
 
 // One lane per query: the reference's two-piece backtrace on the five planes, every test of a step evaluated so that the
-// certificate (exactly one candidate, no phantom below the target of an open test) can be decided.  oracle/dense.hpp
-// traceback2 is the specification.
+// certificate (exactly one candidate, no phantom below the target of an open test) can be decided.
 __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= P.n_queries) return;
