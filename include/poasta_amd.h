@@ -139,6 +139,10 @@ typedef struct poa_stats {
 typedef struct poa_graph poa_graph_t;
 typedef struct poa_batch poa_batch_t;
 
+/* Threading: a poa_graph_t is immutable after poa_graph_create and may be shared by batches on several threads (its bubble
+ * index, needed by exact / hybrid runs only, is built once under a lock).  A poa_batch_t belongs to one thread at a time.
+ * poa_align_batch* are re-entrant on distinct output buffers.  poa_last_error() is thread-local. */
+
 /* ---- library --------------------------------------------------------------------------- */
 const char* poa_version(void);
 const char* poa_last_error(void);     /* thread-local description of the last failure */

@@ -160,6 +160,7 @@ void PlaneWorkspace::release() {
 
 struct poa_graph {
     FlatGraph g;
+    std::mutex bubble_mu;   // the bubble index (exact / hybrid mode only) is built on first use; batches on other threads may share the handle
 };
 
 struct poa_batch {
@@ -205,6 +206,7 @@ struct poa_batch {
     uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0, ex_swpn = 0;
     uint32_t ex_win = 64;              // wave search: priorities in the descriptor ring (power of two)
     uint32_t ex_skew = 0;              // max over nodes of dist_to_end max - min: bounds how far the min-gap heuristic can grow along a greedy extension
+    DevBuf<uint32_t> d_pipeline_error;   // FwdParams::pipeline_error
     DevBuf<unsigned long long> d_ex_prof;
     DevBuf<uint32_t> d_ex_counters;    // wave search: num_queued, num_visited, num_pruned, steps per query
     bool exact_ready = false;
@@ -224,6 +226,17 @@ struct poa_batch {
 };
 
 // sums the HIP-event timings of every run recorded since the last call; the stream must be idle.
+// a wave of the multi-wave pipeline gave up waiting for its neighbour (mw_wait_gt): the planes are not to be trusted
+static int check_pipeline_error(poa_batch* b) {
+    uint32_t w = 0;
+    HIP_TRY(hipMemcpy(&w, b->d_pipeline_error.p, 4, hipMemcpyDeviceToHost));
+    if (w) {
+        (void)hipMemset(b->d_pipeline_error.p, 0, 4);
+        return fail(POA_ERR_HIP, "multi-wave forward pipeline timed out waiting for a neighbouring strip: results discarded");
+    }
+    return POA_OK;
+}
+
 static void collect_stats(poa_batch* b, poa_stats_t* stats) {
     const uint32_t n = b->n_queries;
     const uint32_t keep_flagged = stats->n_flagged;
@@ -412,6 +425,8 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(b->d_scratch.alloc(std::max<uint64_t>(scratch_total, 1)));
     HIP_TRY(b->d_pairs.alloc(std::max<uint64_t>(scratch_total, 1)));
     HIP_TRY(b->d_carry.alloc(std::max<uint64_t>(2ull * max_chunk_any * rows, 1)));
+    HIP_TRY(b->d_pipeline_error.alloc(1));
+    HIP_TRY(hipMemset(b->d_pipeline_error.p, 0, 4));
     if (n_queries) {
         std::string werr;
         if (!b->d_planes.acquire(device, ws + 256, werr)) return fail(POA_ERR_OUT_OF_MEMORY, "score-plane workspace: " + werr);
@@ -445,7 +460,11 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
 static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_config_t* cfg) {
     const FlatGraph& fg = b->graph->g;
     std::string err;
-    int rc = build_bubble_index(const_cast<FlatGraph&>(fg), err);
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<poa_graph*>(b->graph)->bubble_mu);
+        rc = build_bubble_index(const_cast<FlatGraph&>(fg), err);
+    }
     if (rc != POA_OK) return fail(rc, err);
     const uint32_t n = fg.n;
     {
@@ -475,6 +494,9 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     b->ex_win = win;
     const uint32_t stack_cap = (uint32_t)(n + b->max_len + 8), wpn = (uint32_t)((b->max_len + 1 + 63) / 64), swpn = (wpn + 63) / 64;
     if (b->exact_ready && b->ex_n_prio >= n_prio && b->ex_pool_cap >= pool_cap) return POA_OK;
+    // the workspace below is re-allocated: released blocks go to the buffer cache, where another batch may pick them up,
+    // so nothing of an earlier run on this batch may still be in flight
+    if (b->ran) HIP_TRY(hipStreamSynchronize(b->last_stream));
     const uint64_t slots = b->plan[0].max_chunk;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -613,6 +635,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = PL.d_off.p;
         fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
         fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
+        fp.pipeline_error = b->d_pipeline_error.p;
         const uint32_t blocks = (ch.count + 3) / 4;
 #define LAUNCH_FWD(QQ, TT)                                                                                              \
     do {                                                                                                               \
@@ -837,6 +860,10 @@ int poa_batch_fetch(poa_batch_t* b, uint32_t* score, poa_aln_pair_t* pairs, uint
     if (!b->ran) return fail(POA_ERR_INVALID_ARG, "poa_batch_fetch: poa_batch_run has not been called");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->last_stream));
+    {
+        int prc = check_pipeline_error(b);
+        if (prc != POA_OK) return prc;
+    }
     const uint32_t n = b->n_queries;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -893,7 +920,7 @@ int poa_batch_stats(poa_batch_t* b, poa_stats_t* stats) {
     if (b->ran) HIP_TRY(hipStreamSynchronize(b->last_stream));
     std::memset(stats, 0, sizeof(*stats));
     collect_stats(b, stats);
-    return POA_OK;
+    return b->ran ? check_pipeline_error(b) : POA_OK;
 }
 
 int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out) {
@@ -1011,6 +1038,23 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
     rc = poa_batch_run_ex(b, costs, cfg, nullptr);
     const double t2 = now();
     if (rc == POA_OK) rc = poa_batch_fetch(b, score, pairs, pair_off, pair_capacity, flags, stats);
+    // replay out of queue space (POA_FLAG_EXACT_OVERFLOW keeps the dense result): before settling for that, run again with
+    // a queue pool 8x, then 64x the size (unless the caller fixed a tiny budget on purpose: queue_entries_per_cell < 1e-3)
+    if (rc == POA_OK && cfg && cfg->mode != POA_MODE_DENSE && flags && !(cfg->queue_entries_per_cell > 0.f && cfg->queue_entries_per_cell < 1e-3f)) {
+        poa_config_t c2 = *cfg;
+        float f = cfg->queue_entries_per_cell > 0.f ? cfg->queue_entries_per_cell : 0.25f;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            bool over = false;
+            for (uint32_t i = 0; i < n_queries && !over; ++i) over = (flags[i] & POA_FLAG_EXACT_OVERFLOW) != 0;
+            if (!over) break;
+            f *= 8.f;
+            c2.queue_entries_per_cell = f;
+            rc = poa_batch_run_ex(b, costs, &c2, nullptr);
+            if (rc == POA_ERR_OUT_OF_MEMORY) { rc = POA_OK; break; }   // the larger pool does not fit: keep what the first run gave
+            if (rc == POA_OK) rc = poa_batch_fetch(b, score, pairs, pair_off, pair_capacity, flags, stats);
+            if (rc != POA_OK) break;
+        }
+    }
     const double t3 = now();
     poa_batch_destroy(b);
     if (timing) std::fprintf(stderr, "poa_align_batch: create %.2f ms, launch %.2f ms, fetch (sync + copies) %.2f ms, destroy %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);

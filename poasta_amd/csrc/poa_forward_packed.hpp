@@ -121,7 +121,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
         uint32_t m_edge_prev = I16;                                     // from_ring: M[r-1][sbase-1]
         if (MW && from_global) {
             // wave 0 of a later group: the last wave must have finished (and released) the whole previous group
-            mw_wait_gt(&mw_progress[S - 1], prog_base - 1);
+            mw_wait_gt(&mw_progress[S - 1], prog_base - 1, P.pipeline_error);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         const uint32_t sbase = s * W;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
             uint32_t PMl[Q];  // hi half = min over predecessors of M[p][my first column - 1]
             uint32_t in_cq = I16, in_ilast = I16, in_mlast = I16;
             if (from_ring) {
-                mw_wait_gt(&mw_progress[wave - 1], prog_base + r);
+                mw_wait_gt(&mw_progress[wave - 1], prog_base + r, P.pipeline_error);
                 const uint32_t* slot = mw_ring[wave - 1][(prog_base + r) % MW_RING];
                 in_cq = slot[0]; in_ilast = slot[1]; in_mlast = slot[2];
             }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                     if (to_ring) {
                         // back-pressure: the slot I am about to overwrite was read MW_RING rows ago
                         // (the consumer may still look ROW_NEAR rows back from the row it is working on)
-                        if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING);
+                        if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING, P.pipeline_error);
                         if (lane == 63) {
                             uint32_t* slot = mw_ring[wave][(prog_base + r) % MW_RING];
                             slot[0] = cq_out; slot[1] = Ic[NP - 1] >> 16; slot[2] = Mc[NP - 1] >> 16;

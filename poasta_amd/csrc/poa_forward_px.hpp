@@ -359,7 +359,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
         const uint32_t prog_base = g * P.n_rows;
         uint32_t m_edge_prev = I16;  // from_ring: M[r-1][sbase-1]
         if (from_global) {
-            mw_wait_gt(&mw_progress[S - 1], prog_base - 1);  // the whole previous group is done and released
+            mw_wait_gt(&mw_progress[S - 1], prog_base - 1, P.pipeline_error);  // the whole previous group is done and released
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         const uint32_t sbase = s * W;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
             const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
             uint32_t in_cq = I16, in_ilast = I16, in_mlast = I16;
             if (from_ring) {
-                mw_wait_gt(&mw_progress[wave - 1], prog_base + r);
+                mw_wait_gt(&mw_progress[wave - 1], prog_base + r, P.pipeline_error);
                 const uint32_t* slot = mw_ring[wave - 1][(prog_base + r) % MW_RING];
                 in_cq = slot[0]; in_ilast = slot[1]; in_mlast = slot[2];
             }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
 
             if (to_ring) {
                 // back-pressure: the consumer may still look ROW_NEAR rows back from the row it is working on
-                if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING);
+                if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING, P.pipeline_error);
                 if (lane == 63) {
                     uint32_t* slot = mw_ring[wave][(prog_base + r) % MW_RING];
                     slot[0] = cq_out; slot[1] = i_out; slot[2] = m_out;

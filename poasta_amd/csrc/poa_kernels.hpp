@@ -50,6 +50,7 @@ struct FwdParams {
     uint32_t* planes;           // workspace: per query [M | I | D], each n_rows * pitch
     uint32_t* strip_carry;      // [n_queries_in_chunk * n_rows] I carried between strips (long queries)
     uint32_t cost_x, cost_oe, cost_e;
+    uint32_t* pipeline_error;   // one word: set when a wave of the multi-wave pipeline gave up waiting (a protocol bug, not an input)
 };
 
 struct TbParams {
@@ -554,11 +555,16 @@ constexpr int MW_MAX_WAVES = 16;
 constexpr uint32_t MW_RING = 64;
 static_assert(MW_RING >= 2 * ROW_NEAR, "ring must hold the look-back window plus slack");
 
-__device__ __forceinline__ void mw_wait_gt(uint32_t* p, uint32_t v) {
+__device__ __forceinline__ void mw_wait_gt(uint32_t* p, uint32_t v, uint32_t* pipeline_error) {
     uint32_t spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= v) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 27)) break;  // never reached in a correct pipeline; bounds a protocol bug to seconds
+        if (++spins > (1u << 27)) {
+            // never reached in a correct pipeline; bounds a protocol bug to seconds AND reports it: the wave goes on with
+            // stale hand-over data, so the run's results must not be used (poa_batch_fetch / poa_batch_stats return POA_ERR_HIP)
+            if (pipeline_error) __hip_atomic_store(pipeline_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
         const uint32_t prog_base = g * P.n_rows;
         uint32_t m_edge_prev = INF;                                     // from_ring: M[r-1][sbase-1]
         if (MW && from_global) {
-            mw_wait_gt(&mw_progress[S - 1], prog_base - 1);             // the whole previous group is done and released
+            mw_wait_gt(&mw_progress[S - 1], prog_base - 1, P.pipeline_error);             // the whole previous group is done and released
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         const uint32_t sbase = s * W;
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
             uint32_t PM[C], PD[C], PMl[Q];
             uint32_t in_cq = INF, in_ilast = INF, in_mlast = INF, cq_out = INF;
             if (from_ring) {
-                mw_wait_gt(&mw_progress[wave - 1], prog_base + r);
+                mw_wait_gt(&mw_progress[wave - 1], prog_base + r, P.pipeline_error);
                 const uint32_t* slot = mw_ring[wave - 1][(prog_base + r) % MW_RING];
                 in_cq = slot[0]; in_ilast = slot[1]; in_mlast = slot[2];
             }
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
             if (MW) {
                 if (to_ring) {
                     // back-pressure: the consumer may still look ROW_NEAR rows back from the row it is working on
-                    if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING);
+                    if (prog_base + r + ROW_NEAR >= MW_RING) mw_wait_gt(&mw_progress[wave + 1], prog_base + r + ROW_NEAR - MW_RING, P.pipeline_error);
                     if (lane == 63) {
                         uint32_t* slot = mw_ring[wave][(prog_base + r) % MW_RING];
                         slot[0] = cq_out; slot[1] = Ic[C - 1]; slot[2] = Mc[C - 1];
