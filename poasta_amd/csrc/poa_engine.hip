@@ -206,6 +206,7 @@ struct poa_batch {
     uint32_t ex_n_prio = 0, ex_pool_cap = 0, ex_stack_cap = 0, ex_wpn = 0, ex_swpn = 0;
     uint32_t ex_win = 64;              // wave search: priorities in the descriptor ring (power of two)
     uint32_t ex_skew = 0;              // max over nodes of dist_to_end max - min: bounds how far the min-gap heuristic can grow along a greedy extension
+    DevBuf<uint32_t> d_ex_order;         // wave search, persistent scheduling: [0] work counter, [1..] query order
     DevBuf<uint32_t> d_pipeline_error;   // FwdParams::pipeline_error
     DevBuf<unsigned long long> d_ex_prof;
     DevBuf<uint32_t> d_ex_counters;    // wave search: num_queued, num_visited, num_pruned, steps per query
@@ -786,30 +787,68 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < wp.chunk_cap) wp.chunk_cap = (uint32_t)v; }
                 wp.win = win;
                 wp.counters = b->d_ex_counters.p;
-                wp.max_lanes = 63;
+                wp.max_lanes = 16;   // entries tested per step: runs of stale / pruned entries are short (1.85 pops per step)
                 if (const char* lv = getenv("POA_WS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) wp.max_lanes = (uint32_t)v; }
                 wp.prof = nullptr;
                 if (getenv("POA_WS_PROF")) {  // per-phase cycle counts of the wave search (diagnostics)
                     HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
                     wp.prof = b->d_ex_prof.p;
                 }
-                // waves per block: as many as share one staged copy of the graph within half a CU's LDS, at most 16
+                // Lanes per query.  One query per wave (64) with persistent scheduling is the default.  Several queries per wave
+                // (POA_WS_GROUP = 32 / 16 / 8 lanes each, all through one instruction stream) issue fewer instructions in
+                // all but lose: the iteration takes the union of the groups' code paths and every wave waits for its slowest
+                // query (measured on config 2, 10 000 queries: 1.09 s at 64 persistent, 1.83 s at 64 static, 1.49 / 1.85 /
+                // 2.53 s at 32 / 16 / 8).  Waves per block: as many as share one staged copy of the graph, at most 16.
+                uint32_t group = 64;
+                if (const char* gv = getenv("POA_WS_GROUP")) { const int v = atoi(gv); if (v == 8 || v == 16 || v == 32 || v == 64) group = (uint32_t)v; }
                 uint32_t wpb = 16;
                 if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && v <= 16) wpb = (uint32_t)v; }
                 const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 80u * 1024u);
-                bool ring_lds = (uint64_t)wpb * win * 12 <= lds_budget;
-                if (getenv("POA_WS_RING_GLOBAL")) ring_lds = false;
-                const uint64_t ring_bytes = ring_lds ? (uint64_t)wpb * win * 12 : 0;
-                bool stage = graph_lds + ring_bytes <= lds_budget;
-                if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
+                bool ring_lds = false, stage = false;
+                for (;;) {
+                    const uint64_t rb = (uint64_t)wpb * (64 / group) * win * 12;
+                    ring_lds = rb <= lds_budget && !getenv("POA_WS_RING_GLOBAL");
+                    stage = graph_lds + (ring_lds ? rb : 0) <= lds_budget;
+                    if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
+                    if (group == 64 || (ring_lds && stage)) break;
+                    // several queries per wave need everything in LDS: fewer waves per block first, then fewer queries per wave
+                    if (wpb > 2 && !getenv("POA_WS_WAVES")) wpb /= 2; else { group *= 2; if (!getenv("POA_WS_WAVES")) wpb = 16; }
+                }
+                const uint64_t ring_bytes = ring_lds ? (uint64_t)wpb * (64 / group) * win * 12 : 0;
                 wp.graph_lds = stage ? graph_lds : 0;
                 wp.waves_per_block = wpb;
+                wp.group = group;
                 wp.ring_global = nullptr;
                 if (!ring_lds) wp.ring_global = b->d_ex_head.p;  // [slots * 3 * ex_n_prio] holds slots * 3 * win
                 const uint32_t lds_bytes = wp.graph_lds + (uint32_t)ring_bytes;
                 if (lds_bytes > 48u * 1024u)
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(poa_wsearch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                hipLaunchKernelGGL(poa_wsearch_kernel, dim3((ch.count + wpb - 1) / wpb), dim3(64 * wpb), lds_bytes, stream, wp);
+                const uint32_t per_block = wpb * (64 / group);
+                uint32_t n_blocks = (ch.count + per_block - 1) / per_block;
+                wp.work_counter = nullptr; wp.order = nullptr;
+                if (group == 64 && !getenv("POA_WS_STATIC")) {
+                    // persistent waves: as many blocks as are resident at once; queries handed out longest-expected-search
+                    // first (by the dense pass's score: more edits, more buckets).  The sort needs the scores on the host:
+                    // one small copy behind the dense pass of this chunk.
+                    int per_cu = 1, cus = 256;
+                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(poa_wsearch_kernel), (int)(64 * wpb), lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+                    const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
+                    if (n_blocks > resident) {
+                        std::vector<uint32_t> sc(ch.count), ord(ch.count);
+                        HIP_TRY(hipMemcpyAsync(sc.data(), b->d_score.p + ch.first, (size_t)ch.count * 4, hipMemcpyDeviceToHost, stream));
+                        HIP_TRY(hipStreamSynchronize(stream));
+                        for (uint32_t i = 0; i < ch.count; ++i) ord[i] = i;
+                        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c2) { return sc[a] > sc[c2]; });
+                        HIP_TRY(b->d_ex_order.alloc(ch.count + 1));
+                        HIP_TRY(hipMemcpyAsync(b->d_ex_order.p + 1, ord.data(), (size_t)ch.count * 4, hipMemcpyHostToDevice, stream));
+                        HIP_TRY(hipMemsetAsync(b->d_ex_order.p, 0, 4, stream));
+                        HIP_TRY(hipStreamSynchronize(stream));   // `ord` is a host temporary
+                        wp.work_counter = b->d_ex_order.p; wp.order = b->d_ex_order.p + 1;
+                        n_blocks = resident;
+                    }
+                }
+                hipLaunchKernelGGL(poa_wsearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
             } else {
             // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
             // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.

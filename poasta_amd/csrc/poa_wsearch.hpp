@@ -12,6 +12,12 @@
 //      first entry that survives; that one is expanded by its own lane (greedy extension, relaxations, pushes) while the
 //      table and the queue are exactly what the reference's would be at that pop.
 //
+// The search of one query keeps one or two lanes busy, and the replay is bound by instruction issue, so a
+// wave carries SEVERAL queries: groups of GS lanes (64 / 32 / 16 / 8), one query per group, all groups stepping through the
+// same instruction stream — the test of the top entries is per lane anyway, and the expansion of each group's surviving
+// entry runs in that group's lane beside the other groups'.  What is wave-uniform with one query per wave (queue state,
+// the popped run) is group-uniform here and travels by shuffles inside the group.
+//
 // ExactSearch::run_buckets (poa_exact.hpp) is the same schedule one lane at a time; compiled for the host it is diffed
 // against the oracle (tests/test_exact_replay.py), and this kernel is diffed against both on the GPU.
 #pragma once
@@ -30,6 +36,12 @@ struct WSearchParams {
     uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
     uint32_t waves_per_block;
     uint32_t max_lanes;       // entries tested per step (<= 63)
+    uint32_t group;           // lanes per query: 64 (one query per wave), 32, 16 or 8
+    // persistent scheduling (group == 64): the launch holds as many waves as are resident at once; each takes the next
+    // query of `order` (longest expected search first) from `work_counter` until none is left, so that no wave waits for
+    // the slowest member of its block and the longest searches do not start last.  Null: query = block / wave index.
+    uint32_t* work_counter;
+    const uint32_t* order;    // [n_queries] positions within the chunk, or null = identity
     uint32_t* counters;       // optional [4 * total]: num_queued, num_visited, num_pruned, steps (null: not kept)
     unsigned long long* prof; // optional [8 * total] cycles: queue+entries, parallel test, drop, fast expand, generic test+expand; counts
 };
@@ -42,6 +54,9 @@ __device__ __forceinline__ uint32_t ws_wave_sum(uint32_t v) {
 
 template <int AS>
 __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const ExactGraph& G, uint32_t* ring, uint32_t lane, uint32_t wave);
+template <int AS, int GS>
+__device__ __forceinline__ void ws_search_groups(const WSearchParams& P, const ExactGraph& G, uint32_t* ring0, uint32_t lane, uint32_t wave);
+
 
 __global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -70,24 +85,157 @@ __global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) {
     }
     // (the wave index is uniform: say so, and every per-query pointer below lives in scalar registers)
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // descriptor ring of this wave: LDS, or (a priority range too wide for it) the slot's slice of P.ring_global
-    uint32_t* ring = P.ring_global ? nullptr : reinterpret_cast<uint32_t*>(lds + P.graph_lds) + (uint64_t)wave * 3 * P.win;
-    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;
-    if (P.ring_global && slot < P.E.n_queries) ring = P.ring_global + (uint64_t)slot * 3 * P.win;
-    if (ring) for (uint32_t i = lane; i < 3 * P.win; i += 64) ring[i] = BQ_EMPTY;
+    // descriptor rings of this wave (one per query it carries): LDS, or (a priority range too wide for it) slices of P.ring_global
+    const uint32_t qpw = 64u / P.group;   // queries per wave
+    uint32_t* ring = P.ring_global ? nullptr : reinterpret_cast<uint32_t*>(lds + P.graph_lds) + (uint64_t)wave * qpw * 3 * P.win;
+    const uint32_t slot0 = (blockIdx.x * P.waves_per_block + wave) * qpw;   // first query slot of this wave
+    if (P.ring_global && slot0 < P.E.n_queries) ring = P.ring_global + (uint64_t)slot0 * 3 * P.win;
+    if (ring) {
+        const uint32_t nring = min(qpw, P.E.n_queries > slot0 ? P.E.n_queries - slot0 : 0u) * 3 * P.win;
+        for (uint32_t i = lane; i < nring; i += 64) ring[i] = BQ_EMPTY;
+    }
     __syncthreads();
-    if (slot >= P.E.n_queries) return;
+    if (slot0 >= P.E.n_queries) return;
     // graph arrays and descriptor ring both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers
-    if (P.graph_lds && !P.ring_global) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS>(P, G, ring, lane, wave);
-    else ws_search_query<0>(P, G, ring, lane, wave);
+    const bool lds_all = P.graph_lds && !P.ring_global;
+    if (P.group == 64) {
+        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS>(P, G, ring, lane, wave);
+        else ws_search_query<0>(P, G, ring, lane, wave);
+    } else {
+        // (the host asks for groups only with graph and rings in LDS)
+        if (P.group == 32) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 32>(P, G, ring, lane, wave);
+        else if (P.group == 16) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 16>(P, G, ring, lane, wave);
+        else ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 8>(P, G, ring, lane, wave);
+    }
+}
+
+// ---- several queries per wave: one per group of GS lanes ------------------------------------------------------------------
+template <int AS, int GS>
+__device__ __forceinline__ void ws_search_groups(const WSearchParams& P, const ExactGraph& G, uint32_t* ring0, uint32_t lane, uint32_t wave) {
+    const ExactParams& E = P.E;
+    constexpr uint32_t QPW = 64u / GS;
+    const uint32_t grp = lane / GS, gl = lane % GS, gbase = grp * GS;
+    const uint32_t slot = (blockIdx.x * P.waves_per_block + wave) * QPW + grp;
+    const bool have = slot < E.n_queries;
+    const uint32_t qi = E.first_query + (have ? slot : 0u);
+    bool live = have && !(E.hybrid && E.dense_flags[qi] == 0);
+    const uint64_t qbeg = E.qoff[qi];
+    const uint32_t L = (uint32_t)(E.qoff[qi + 1] - qbeg);
+    const uint32_t wslot = have ? slot : 0u;   // a group without a query computes addresses of slot 0 and never uses them
+    ExactWork W;
+    W.T = E.planes + E.plane_off[qi];
+    W.n_rows = E.G.n_rows;
+    W.pitch = E.pitch[qi];
+    W.reached = E.reached + (uint64_t)wslot * E.G.n_exit * E.wpn;
+    W.rsum = E.rsum + (uint64_t)wslot * E.G.n_exit * E.swpn;
+    W.wpn = E.wpn; W.swpn = E.swpn;
+    W.head = nullptr; W.n_prio = 0xFFFFFFFFu;
+    W.pool = nullptr; W.pool_cap = 0;
+    W.stack = E.stack + (uint64_t)wslot * E.stack_cap;
+    W.stack_cap = E.stack_cap;
+    W.bq_desc = ring0 + (uint64_t)grp * 3 * P.win; W.bq_win = P.win;
+    W.bq_chunks = P.chunks + (uint64_t)wslot * P.chunk_cap * BQ_CHUNK;
+    W.bq_chunk_cap = P.chunk_cap;
+
+    ExactSearchT<AS> S(G, W, E.qseq + qbeg, L, E.C);
+    ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+    uint32_t end_score = EX_INF, found = 0, steps = 0;
+    // group-uniform state lives identically in every lane of the group; what one lane changes alone is handed round afterwards
+    auto from_lane = [&](uint32_t v, uint32_t src) { return (uint32_t)__shfl((int)v, (int)(gbase + src), 64); };
+    auto adopt = [&](uint32_t src) {
+        S.err = from_lane(S.err, src);
+        S.layer_min = from_lane(S.layer_min, src);
+        S.bq_live = from_lane(S.bq_live, src);
+        S.bq_hi = from_lane(S.bq_hi, src);
+        S.bq_chunk_top = from_lane(S.bq_chunk_top, src);
+        S.bq_free = from_lane(S.bq_free, src);
+        found = from_lane(found, src);
+        end_score = from_lane(end_score, src);
+        R.end_row = from_lane(R.end_row, src);
+        R.end_off = from_lane(R.end_off, src);
+    };
+    if (live && gl == 0) S.push_initial_states();
+    adopt(0);
+    S.bq_wr = gl == 0;
+    const uint32_t cap = P.max_lanes < (uint32_t)GS ? P.max_lanes : (uint32_t)GS;
+
+    // every lane runs the loop until no group of the wave has work left (shuffles need the whole wave inside)
+    while (__any(live && !found && !S.err)) {
+        const bool go = live && !found && !S.err;
+        uint32_t st = 0; BqDesc d{0, 0};
+        if (go && !S.bq_current(st, d)) S.err = EX_PANIC;   // "Could not align sequence!" (astar.rs:142-144)
+        const bool run = go && !S.err;
+        const uint32_t nb = run ? (d.n_top < cap ? d.n_top : cap) : 0u;
+        const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
+        const bool act = gl < nb;
+        ExU4 e{0, 0, 0, 0};
+        uint32_t prev = EX_NIL;
+        if (run) { prev = ch[0].x; if (act) e = ch[d.n_top - gl]; }
+        uint32_t sk = 1;
+        typename ExactSearchT<AS>::FastItem F{0, 0, 0, 0, 0};
+        if (act) sk = S.inspect_fast(e.x, e.y, e.z, st, F);
+        const uint64_t stop_w = __ballot(act && (sk == 0 || sk == 3 || S.err != 0));
+        const uint32_t stop = (uint32_t)((stop_w >> gbase) & ((GS == 64) ? ~0ull : ((1ull << GS) - 1)));
+        const uint32_t n = stop ? (uint32_t)__builtin_ctz(stop) : nb;
+        if (run) {
+            if (gl < n && sk == 2) S.num_pruned += 1;   // per-lane tallies, summed at the end
+            if (gl > n) S.err = 0;                      // tests beyond the run are discarded with whatever they hit
+            S.bq_drop(st, d, n < nb ? n + 1 : nb, prev);
+            steps += 1;
+        }
+        const bool expand = run && n < nb;
+        if (expand && gl == n && !S.err) {
+            S.bq_wr = true;
+            if (F.kind) found = S.process_fast(e.x, e.y, e.z, st, F, R, end_score) ? 1u : 0u;
+            else {
+                if (sk == 3) sk = S.inspect_skip(e.x, e.y, e.z, st);
+                if (sk == 2) S.num_pruned += 1;
+                if (sk == 0 && !S.err) found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+            }
+            S.bq_wr = gl == 0;
+        }
+        // (every lane shuffles; a group that did not expand takes its own lane 0's values, i.e. nothing changes)
+        adopt(expand ? n : 0u);
+    }
+
+    uint32_t nq = S.num_queued, nv = S.num_visited, np = S.num_pruned;
+    for (int o = GS / 2; o; o >>= 1) {
+        nq += (uint32_t)__shfl_xor((int)nq, o, 64); nv += (uint32_t)__shfl_xor((int)nv, o, 64); np += (uint32_t)__shfl_xor((int)np, o, 64);
+    }
+    if (live && gl == 0) {
+        E.status[qi] = S.err ? S.err : (found ? EX_OK : EX_PANIC);
+        E.end_cell[2 * qi] = R.end_row;
+        E.end_cell[2 * qi + 1] = R.end_off;
+        if (P.counters) { P.counters[4 * qi] = nq; P.counters[4 * qi + 1] = nv; P.counters[4 * qi + 2] = np; P.counters[4 * qi + 3] = steps; }
+    }
 }
 
 template <int AS>
 __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const ExactGraph& G, uint32_t* ring, uint32_t lane, uint32_t wave) {
     const ExactParams& E = P.E;
-    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;
-    const uint32_t qi = E.first_query + slot;
-    if (E.hybrid && E.dense_flags[qi] == 0) return;
+    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;   // this wave's workspace (reached sets, stack, chunks, ring)
+    bool first = true;
+    for (;;) {
+    uint32_t pos = slot;
+    if (P.work_counter) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(P.work_counter, 1u);
+        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (pos >= E.n_queries) return;
+        if (P.order) pos = P.order[pos];
+    } else if (!first) return;
+    const uint32_t qi = E.first_query + pos;
+    if (E.hybrid && E.dense_flags[qi] == 0) { first = false; continue; }
+    if (!first || P.work_counter) {
+        // the workspace of the previous search of this wave: reached sets back to empty, ring back to empty
+        // (the host clears nothing in persistent mode)
+        uint64_t* z = E.reached + (uint64_t)slot * E.G.n_exit * E.wpn;
+        for (uint64_t i = lane; i < (uint64_t)E.G.n_exit * E.wpn; i += 64) z[i] = 0;
+        uint64_t* zs = E.rsum + (uint64_t)slot * E.G.n_exit * E.swpn;
+        for (uint64_t i = lane; i < (uint64_t)E.G.n_exit * E.swpn; i += 64) zs[i] = 0;
+        for (uint32_t i = lane; i < 3 * P.win; i += 64) ring[i] = BQ_EMPTY;
+    }
+    first = false;
     const uint64_t qbeg = E.qoff[qi];
     const uint32_t L = (uint32_t)(E.qoff[qi + 1] - qbeg);
     ExactWork W;
@@ -179,6 +327,7 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
             P.counters[4 * qi] = nq; P.counters[4 * qi + 1] = nv; P.counters[4 * qi + 2] = np; P.counters[4 * qi + 3] = steps;
         }
     }
+    }  // next query of this wave
 }
 
 }  // namespace poa_amd
