@@ -419,9 +419,6 @@ public:
     POA_HD void queue_state(uint32_t row, uint32_t off, uint32_t st, uint32_t new_score) {
         const uint32_t pr64 = new_score + h(row, off, st);
         num_queued += 1;
-#ifdef EX_TRACE
-        printf("  push g=%u row=%u off=%u st=%u\n", new_score, row, off, st);
-#endif
         if (W.bq_desc) { bq_push(pr64, st, new_score, row, off); return; }
         if (pr64 >= W.n_prio || pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; }
         const uint32_t prio = pr64;
@@ -873,9 +870,6 @@ public:
             if (err) break;
             bq_drop(st, d, n < nb ? n + 1 : nb, ch[0].x);
             if (n < nb) {
-#ifdef EX_TRACE
-                printf("pop g=%u row=%u off=%u st=%u kind=%u layer=%u\n", e.x, e.y, e.z, st, F.kind, layer_min);
-#endif
                 if (F.kind) found = process_fast(e.x, e.y, e.z, st, F, R, end_score);
                 else found = process_popped(e.x, e.y, e.z, st, R, end_score);
             }
