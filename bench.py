@@ -314,7 +314,20 @@ def _cpu_info():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return model, (len(phys) or usable), usable
+    quota = None   # cgroup CPU quota of this job in cores (the GPU boxes give a one-GPU job a share of the host)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = round(q / per, 2)
+        except (OSError, ValueError):
+            pass
+    return model, (len(phys) or usable), usable, quota
 
 
 def cpu_baseline(graph, qs, n_rows):
@@ -323,7 +336,7 @@ def cpu_baseline(graph, qs, n_rows):
     and one thread.  A reported baseline, not the target."""
     from oracle import pyoracle
     from poasta_amd.graph import pack_queries
-    model, phys, usable = _cpu_info()
+    model, phys, usable, quota = _cpu_info()
     max_threads = max(1, min(phys, usable))
     og = pyoracle.OracleGraph.from_csr(graph.as_dict())
     qseq, qoff = pack_queries(qs)
@@ -352,7 +365,7 @@ def cpu_baseline(graph, qs, n_rows):
              "sample": "%d queries of the same workload, A* + min-gap heuristic + superbubble pruning + backtrace (C++ restatement of "
                        "the reference CPU path, -O3), %d threads (fastest of the sweep below; %d physical cores usable), %.2f s wall" % (len(qs), threads, max_threads, dt),
              "thread_sweep_gcells": {str(t): round(int(n_rows * (qoff[1:ns + 1] - qoff[:ns] + 1).astype("int64").sum()) / v / 1e9, 4) for t, v in sweep.items()},
-             "cpu_model": model, "physical_cores": phys, "usable_cpus": usable,
+             "cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "cgroup_cpu_quota_cores": quota,
              "aligned_bases_per_sec": round(int(qoff[-1]) / dt, 1),
              "visited_states_per_sec": round(float(A["counters"][:, 1].sum()) / dt, 1),
              "single_thread": {"value": round(cells1 / dt1 / 1e9, 5), "unit": "Gcells/s (matrix-equivalent)", "cores": 1,
