@@ -286,3 +286,47 @@ def test_gpu_exact_overflow_keeps_dense_result(engine, oracle):
         if int(x.flags[i]) & 0x40:  # POA_FLAG_EXACT_OVERFLOW: dense result kept
             assert int(x.score[i]) == int(d.score[i]) and x.raw_alignment(i) == d.raw_alignment(i)
     assert any(int(f) & 0x40 for f in x.flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(POA_WS_RING_GLOBAL="1"), dict(POA_WS_GROUP="16"), dict(POA_WS_GROUP="8", POA_WS_WAVES="2"),
+                                 dict(POA_WS_STATIC="1"), dict(POA_WS_LANES="1"), dict(POA_WS_LANES="63", POA_WS_WAVES="4"),
+                                 dict(POA_EXACT_LDS="0"), dict(POA_EXACT_IMPL="lane")],
+                         ids=["ring_in_global_memory", "four_queries_per_wave", "eight_queries_per_wave", "static_schedule",
+                              "one_entry_per_step", "63_entries_per_step", "graph_in_global_memory", "one_search_per_lane_kernel"])
+def test_gpu_replay_variants_are_bit_identical(engine, oracle, env):
+    """Every schedule / placement variant of the replay kernel returns the reference's alignments: the descriptor ring in
+    global memory (wide priority ranges), several queries per wave, the static schedule, single-entry and 63-entry steps,
+    the graph read from global memory, and the round-1 one-search-per-lane kernel."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        g, (qseq, qoff) = W.config2(n_queries=40)
+        qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(40)]
+        n, res = _gpu_exact_vs_astar(engine, oracle, g, qs)
+        assert n == 40 and res.stats["n_exact"] == 40
+        poa = W.LayeredPOA(n_layers=60, width=4, indeg=4, seed=5)
+        assert _gpu_exact_vs_astar(engine, oracle, poa.graph, poa.queries(6, length=0))[0] == 6
+        pg = W.PangenomePOA(ref_len=400, n_hap=6, p_snp=0.02, p_indel=0.01, max_indel=6, seed=4)
+        assert _gpu_exact_vs_astar(engine, oracle, pg.graph, pg.queries(6, length=150))[0] == 6
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+def test_gpu_search_counters_equal_the_reference(engine, oracle):
+    """AstarResult::{num_queued, num_visited, num_pruned} of the replayed search (astar.rs:86-89) through the C ABI."""
+    g, (qseq, qoff) = W.config2(n_queries=24)
+    rb = engine.ResidentBatch(g, qseq, qoff)
+    rb.run(engine.GapAffine(4, 2, 6), None, engine.make_config("exact", queue_entries_per_cell=0.25))
+    sc = rb.search_counters()
+    rb.fetch()
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=8, want_counters=True)
+    assert np.array_equal(sc[:, :3].astype(np.uint64), A["counters"])
+    assert (sc[:, 3] > 0).all() and (sc[:, 3] <= sc[:, 0]).all()   # steps: at most one per queued state
+    rb.close()
