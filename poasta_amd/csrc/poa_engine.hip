@@ -821,8 +821,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 wp.ring_global = nullptr;
                 if (!ring_lds) wp.ring_global = b->d_ex_head.p;  // [slots * 3 * ex_n_prio] holds slots * 3 * win
                 const uint32_t lds_bytes = wp.graph_lds + (uint32_t)ring_bytes;
+                const void* kfn = group == 64 ? reinterpret_cast<const void*>(poa_wsearch_kernel) : reinterpret_cast<const void*>(poa_wsearch_groups_kernel);
                 if (lds_bytes > 48u * 1024u)
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(poa_wsearch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                    HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 const uint32_t per_block = wpb * (64 / group);
                 uint32_t n_blocks = (ch.count + per_block - 1) / per_block;
                 wp.work_counter = nullptr; wp.order = nullptr;
@@ -848,7 +849,8 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                         n_blocks = resident;
                     }
                 }
-                hipLaunchKernelGGL(poa_wsearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
+                if (group == 64) hipLaunchKernelGGL(poa_wsearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
+                else hipLaunchKernelGGL(poa_wsearch_groups_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
             } else {
             // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
             // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.

@@ -58,7 +58,10 @@ template <int AS, int GS>
 __device__ __forceinline__ void ws_search_groups(const WSearchParams& P, const ExactGraph& G, uint32_t* ring0, uint32_t lane, uint32_t wave);
 
 
-__global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) {
+// graph staging + ring set-up shared by the two kernels; GROUPS: several queries per wave (its own kernel, so that the
+// default one-query-per-wave kernel keeps its registers: the union of both needs scratch)
+template <bool GROUPS>
+__device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const ExactParams& E = P.E;
     ExactGraph G = E.G;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) {
     if (slot0 >= P.E.n_queries) return;
     // graph arrays and descriptor ring both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers
     const bool lds_all = P.graph_lds && !P.ring_global;
-    if (P.group == 64) {
+    if constexpr (!GROUPS) {
         if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS>(P, G, ring, lane, wave);
         else ws_search_query<0>(P, G, ring, lane, wave);
     } else {
@@ -108,6 +111,11 @@ __global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) {
         else ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 8>(P, G, ring, lane, wave);
     }
 }
+
+__global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) { ws_kernel_body<false>(P); }
+__global__ __launch_bounds__(1024) void poa_wsearch_groups_kernel(WSearchParams P) { ws_kernel_body<true>(P); }
+
+
 
 // ---- several queries per wave: one per group of GS lanes ------------------------------------------------------------------
 template <int AS, int GS>

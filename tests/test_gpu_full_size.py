@@ -102,3 +102,24 @@ def test_config4_members(engine, oracle):
     _check_batch_independence(engine, g, qs, res, idx)
     _check_shape(res, qoff, range(0, 96, 3))
     rb.close()
+
+
+def test_config2_hybrid_full_size_is_the_reference(engine, oracle):
+    """configs[1] at full size in hybrid mode (dense pass + replay of the reference's search for every query the dense pass
+    cannot certify): ALL 10 000 scores and alignments equal the restated reference's (A*, min-gap heuristic, pruning), and so
+    do its search counters for the replayed queries."""
+    g, (qseq, qoff) = W.config2(n_queries=10000)
+    rb = engine.ResidentBatch(g, qseq, qoff)
+    rb.run(_costs(engine), None, engine.make_config("hybrid", queue_entries_per_cell=0.25))
+    sc = rb.search_counters()
+    res = rb.fetch()
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=16, want_counters=True)
+    assert int((A["status"] != 0).sum()) == 0
+    assert np.array_equal(res.score, A["score"])
+    assert int((res.flags != 0).sum()) == 0 and res.stats["n_exact"] == 9928
+    bad = [i for i in range(10000) if res.raw_alignment(i) != oracle.batch_alignment(A, i)]
+    assert bad == []
+    replayed = sc[:, 3] > 0
+    assert int(replayed.sum()) == 9928 and np.array_equal(sc[replayed, :3].astype(np.uint64), A["counters"][replayed])
+    rb.close()
