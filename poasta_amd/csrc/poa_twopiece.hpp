@@ -12,10 +12,10 @@
 //   I2[v][j+1] = min( I1[v][j], I2[v][j] ) + e2                                min-plus prefix scan over I1, decay e2
 //   M [v][j] = min( H, I1, I2 )                                                end row: no I, D1 only by extension
 //
-// One wavefront per query, rows in topological order, 64 columns per pass with the scan carries kept in registers; predecessor
-// rows are re-read from the planes (just written by this wave: L2).  u32 arithmetic, INF absorbing.  This is the plain
-// kernel of the model — parity first; the packed-u16 pairs-across-quads mapping of the one-piece kernels carries over
-// (two more packed recurrences per register) and is the next step for it.
+// One wavefront per query, rows in topological order, four columns per lane and 256 per pass with the scan carries kept in
+// registers; predecessor rows are re-read from the planes (just written by this wave: L2).  u32 arithmetic, INF absorbing.
+// This is the u32 kernel of the model (20 bytes written per cell: HBM-bound territory); the packed-u16 pairs-across-quads
+// mapping of the one-piece kernels carries over (two more packed recurrences per register) and is the next step for it.
 // Traceback: the reference's rule (gap_affine_2piece.rs:639-794, :944-1043) on the five planes with the same uniqueness
 // certificate as the one-piece pass; one lane per query (a chain of dependent reads; the speculative walk of
 // poa_traceback_kernel is not ported to five planes yet).
@@ -45,7 +45,22 @@ __device__ __forceinline__ uint32_t tp_sat(uint32_t a, uint32_t b) {
     return r < a ? 0xFFFFFFFFu : r;
 }
 
+// inclusive min-plus scan over the lanes with a constant decay per lane step: out(l) = min over l' <= l of v(l') + (l - l') * step
+__device__ __forceinline__ uint32_t tp_scan(uint32_t v, uint32_t step, uint32_t lane) {
+#pragma unroll
+    for (uint32_t s = 1; s < 64; s <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, (int)s, 64);
+        if (lane >= s) v = min(v, tp_sat(t, s * step));
+    }
+    return v;
+}
+
+// Four consecutive columns per lane, 256 columns per pass: every plane access is one 16-byte load / store per lane, 1 KiB
+// contiguous per wave-instruction; the insertion recurrences run as a 4-step chain in the lane plus one wave scan per
+// pass and plane (I1 with decay 4*e1 per lane, I2 over the finished I1 with decay 4*e2), carries between passes in registers.
 __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
+    constexpr int K = 4;
+    constexpr uint32_t INF = 0xFFFFFFFFu;
     const uint32_t slot = blockIdx.x, lane = threadIdx.x;
     const uint32_t qi = P.first_query + slot;
     const uint64_t qbeg = P.qoff[qi];
@@ -54,63 +69,107 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
     const uint64_t plane = (uint64_t)P.n_rows * P.pitch;
     uint32_t* M = P.planes + (uint64_t)slot * 5 * plane;
     uint32_t* I1 = M + plane; uint32_t* D1 = I1 + plane; uint32_t* I2 = D1 + plane; uint32_t* D2 = I2 + plane;
-    const uint32_t INF = 0xFFFFFFFFu;
+    const uint32_t n_pass = (L + 1 + 255) / 256;   // pitch is a multiple of 64: a pass may end inside the row's padding
     for (uint32_t r = 0; r < P.n_rows; ++r) {
         const RowMeta rm = P.rows[r];
         const bool is_end = r == P.end_row, is_start = r == P.start_row;
         const uint64_t ro = (uint64_t)r * P.pitch;
-        // scan carries: I1 / I2 of the last column done, and what that column would open
-        uint32_t cI1 = INF, cI2 = INF, cA = INF;
-        for (uint32_t j0 = 0; j0 <= L; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            const bool in = j <= L;
-            const uint8_t qj = (in && j < L) ? q[j] : 0, qjm = (in && j > 0) ? q[j - 1] : 0;
-            uint32_t pm = INF, pd = INF, pd2 = INF, pml = INF;
+        uint32_t c1 = INF, c2 = INF;   // I1 / I2 entering the first column of the pass
+        uint32_t cpm = INF;             // min over predecessors of M[p][first column of the pass - 1]
+        for (uint32_t ps = 0; ps < n_pass; ++ps) {
+            const uint32_t j = ps * 256 + K * lane;   // my first column
+            const bool in = j < P.pitch;              // (whole 16-byte groups lie inside or outside the plane row)
+            uint32_t qs[K], qm;                       // q[j + k] (0 past the end: never a symbol), q[j - 1]
+#pragma unroll
+            for (int k = 0; k < K; ++k) qs[k] = (j + k < L) ? (uint32_t)q[j + k] : 0u;
+            qm = (j > 0 && j - 1 < L) ? (uint32_t)q[j - 1] : 0u;
+            uint32_t pm[K], pd[K], pd2[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { pm[k] = INF; pd[k] = INF; pd2[k] = INF; }
             if (in)
-                for (uint32_t k = 0; k < rm.pred_count; ++k) {
-                    const uint64_t po = (uint64_t)P.pred_rows[rm.pred_begin + k] * P.pitch + j;
-                    pm = min(pm, M[po]); pd = min(pd, D1[po]); pd2 = min(pd2, D2[po]);
-                    if (j > 0) pml = min(pml, M[po - 1]);
+                for (uint32_t e = 0; e < rm.pred_count; ++e) {
+                    const uint64_t po = (uint64_t)P.pred_rows[rm.pred_begin + e] * P.pitch + j;
+                    const uint4 a = *reinterpret_cast<const uint4*>(M + po), b = *reinterpret_cast<const uint4*>(D1 + po),
+                                c = *reinterpret_cast<const uint4*>(D2 + po);
+                    pm[0] = min(pm[0], a.x); pm[1] = min(pm[1], a.y); pm[2] = min(pm[2], a.z); pm[3] = min(pm[3], a.w);
+                    pd[0] = min(pd[0], b.x); pd[1] = min(pd[1], b.y); pd[2] = min(pd[2], b.z); pd[3] = min(pd[3], b.w);
+                    pd2[0] = min(pd2[0], c.x); pd2[1] = min(pd2[1], c.y); pd2[2] = min(pd2[2], c.z); pd2[3] = min(pd2[3], c.w);
                 }
-            uint32_t d1 = tp_sat(pd, P.e1);
-            if (!is_end && (j >= L || rm.sym != qj)) d1 = min(d1, tp_sat(pm, P.oe));   // openD: the row mismatches q[j], or the query is exhausted
-            const uint32_t d2 = tp_sat(min(pd, pd2), P.e2);
-            uint32_t diag = INF;
-            if (is_end) diag = pm;                                                      // M[u][j] -> M[end][j], cost 0
-            else if (j > 0) diag = tp_sat(pml, rm.sym != qjm ? P.x : 0u);
-            uint32_t h = min(diag, min(d1, d2));
-            if (is_start && j == 0) h = 0;
-            if (!in) h = INF;
-            // openI(v, j): an edge to end, or a non-end child that mismatches q[j]  (RowMeta: ALWAYS / NEVER / the one child symbol)
-            bool open_i = false;
-            if (in && j < L && !is_end) {
-                if (rm.flags & ROW_OPENI_ALWAYS) open_i = true;
-                else if (rm.flags & ROW_OPENI_NEVER) open_i = false;
-                else open_i = rm.child_sym != qj;
+            // M of the predecessors one column to the left of my first column
+            uint32_t pml = (uint32_t)__shfl_up((int)pm[K - 1], 1, 64);
+            if (lane == 0) pml = cpm;
+            cpm = (uint32_t)__shfl((int)pm[K - 1], 63, 64);
+            uint32_t h[K], d1[K], d2[K], a[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t col = j + k;
+                const bool col_in = col <= L;
+                d1[k] = tp_sat(pd[k], P.e1);
+                if (!is_end && (col >= L || rm.sym != qs[k])) d1[k] = min(d1[k], tp_sat(pm[k], P.oe));   // openD
+                d2[k] = tp_sat(min(pd[k], pd2[k]), P.e2);
+                const uint32_t left = k == 0 ? pml : pm[k - 1];
+                const uint32_t ql = k == 0 ? qm : qs[k - 1];
+                uint32_t diag = INF;
+                if (is_end) diag = pm[k];
+                else if (col > 0) diag = tp_sat(left, rm.sym != ql ? P.x : 0u);
+                h[k] = min(diag, min(d1[k], d2[k]));
+                if (is_start && col == 0) h[k] = 0;
+                if (!col_in) { h[k] = INF; d1[k] = INF; d2[k] = INF; }
+                bool open_i = false;
+                if (col < L && !is_end) {
+                    if (rm.flags & ROW_OPENI_ALWAYS) open_i = true;
+                    else if (rm.flags & ROW_OPENI_NEVER) open_i = false;
+                    else open_i = rm.child_sym != qs[k];
+                }
+                a[k] = open_i ? tp_sat(h[k], P.oe) : INF;   // what column col opens INTO col + 1
             }
-            const uint32_t a = open_i ? tp_sat(h, P.oe) : INF;   // what column j opens INTO column j + 1
-            // I1[j] = min over k <= j of (B[k] + (j - k) e1), B[k] = what enters column k from k - 1
-            const uint32_t a_left = (uint32_t)__shfl_up((int)a, 1, 64);
-            uint32_t v1 = lane == 0 ? min(tp_sat(cI1, P.e1), cA) : a_left;
-            if (j0 == 0 && lane == 0) v1 = INF;                   // I1[v][0] = INF
-            for (uint32_t s = 1; s < 64; s <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)v1, (int)s, 64);
-                if (lane >= s) v1 = min(v1, tp_sat(t, s * P.e1));
+            // I1: chain inside the lane with nothing entering, then what enters from the left
+            uint32_t v1[K];
+            v1[0] = INF;
+#pragma unroll
+            for (int k = 1; k < K; ++k) v1[k] = min(tp_sat(v1[k - 1], P.e1), a[k - 1]);
+            const uint32_t out1 = min(tp_sat(v1[K - 1], P.e1), a[K - 1]);   // leaves my last column towards the next lane
+            const uint32_t s1 = tp_scan(out1, K * P.e1, lane);
+            uint32_t in1 = (uint32_t)__shfl_up((int)s1, 1, 64);
+            if (lane == 0) in1 = INF;
+            in1 = min(in1, tp_sat(c1, lane * K * P.e1));
+            if (ps == 0 && lane == 0) in1 = INF;                            // I1[v][0] = INF
+#pragma unroll
+            for (int k = 0; k < K; ++k) v1[k] = min(v1[k], tp_sat(in1, (uint32_t)k * P.e1));
+            c1 = min((uint32_t)__shfl((int)s1, 63, 64), tp_sat(c1, 64 * K * P.e1));
+            // I2 over the finished I1: I2[c] = min(I1[c-1], I2[c-1]) + e2
+            const uint32_t i1_left = in1;                                    // == I1 of my first column
+            uint32_t v2[K];
+            v2[0] = INF;
+#pragma unroll
+            for (int k = 1; k < K; ++k) v2[k] = tp_sat(min(v2[k - 1], v1[k - 1]), P.e2);
+            const uint32_t out2 = tp_sat(min(v2[K - 1], v1[K - 1]), P.e2);
+            const uint32_t s2 = tp_scan(out2, K * P.e2, lane);
+            uint32_t in2 = (uint32_t)__shfl_up((int)s2, 1, 64);
+            if (lane == 0) in2 = INF;
+            in2 = min(in2, tp_sat(c2, lane * K * P.e2));
+            if (ps == 0 && lane == 0) in2 = INF;
+            (void)i1_left;
+#pragma unroll
+            for (int k = 0; k < K; ++k) v2[k] = min(v2[k], tp_sat(in2, (uint32_t)k * P.e2));
+            c2 = min((uint32_t)__shfl((int)s2, 63, 64), tp_sat(c2, 64 * K * P.e2));
+            if (is_end) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { v1[k] = INF; v2[k] = INF; }
             }
-            // I2[j] = min over k <= j of (B2[k] + (j - k) e2), B2[k] = I1[k-1] + e2
-            const uint32_t i1_left = (uint32_t)__shfl_up((int)v1, 1, 64);
-            uint32_t v2 = lane == 0 ? tp_sat(min(cI1, cI2), P.e2) : tp_sat(i1_left, P.e2);
-            if (j0 == 0 && lane == 0) v2 = INF;
-            for (uint32_t s = 1; s < 64; s <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)v2, (int)s, 64);
-                if (lane >= s) v2 = min(v2, tp_sat(t, s * P.e2));
-            }
-            if (is_end) { v1 = INF; v2 = INF; }
             if (in) {
-                M[ro + j] = min(h, min(v1, v2));
-                I1[ro + j] = v1; D1[ro + j] = d1; I2[ro + j] = v2; D2[ro + j] = d2;
+                uint32_t m[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    m[k] = min(h[k], min(v1[k], v2[k]));
+                    if (j + k > L) { m[k] = INF; v1[k] = INF; v2[k] = INF; }   // padding columns read as unvisited
+                }
+                *reinterpret_cast<uint4*>(M + ro + j) = make_uint4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<uint4*>(I1 + ro + j) = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+                *reinterpret_cast<uint4*>(D1 + ro + j) = make_uint4(d1[0], d1[1], d1[2], d1[3]);
+                *reinterpret_cast<uint4*>(I2 + ro + j) = make_uint4(v2[0], v2[1], v2[2], v2[3]);
+                *reinterpret_cast<uint4*>(D2 + ro + j) = make_uint4(d2[0], d2[1], d2[2], d2[3]);
             }
-            cI1 = (uint32_t)__shfl((int)v1, 63, 64); cI2 = (uint32_t)__shfl((int)v2, 63, 64); cA = (uint32_t)__shfl((int)a, 63, 64);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the next rows read this one back (same wave)
     }
