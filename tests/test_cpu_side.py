@@ -298,3 +298,21 @@ def test_mingap_with_pruning_can_be_suboptimal(oracle):
     assert int(D["score"][4]) == 500 and int(mg["score"][4]) == 500 and int(mg_p["score"][4]) == 501
     assert int(D["score"][9]) == 488 and int(mg["score"][9]) == 489 and int(D["flags"][9]) & 2
     assert all(int(mg_p["score"][i]) == int(D["score"][i]) for i in ok if i not in (4, 9))
+
+
+def test_bench_spawns_its_own_launcher_for_n_gpus():
+    """`python bench.py --gpus 2` with no launcher in the environment starts torch.distributed.run itself (as a child, before
+    anything touches a GPU) and hands back its exit code.  Here, without a GPU, both ranks must get as far as the engine's
+    "needs a GPU" exit — which proves the spawn, the rendezvous arguments and that rank discovery reads the launcher's env."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode(errors="replace")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the rehearsal itself runs (covered on the GPU box)")
+    assert p.returncode != 0
+    assert err.count("bench.py needs a GPU") >= 1, err[-2000:]
+    assert "--nproc-per-node" not in err or "error: unrecognized" not in err
