@@ -184,18 +184,20 @@ def main():
     # ---- device -> host copy of one step's results (SURVEY.md §8(d) counts it; `value` does not) ----
     incl_d2h = None
     if not args.no_extras:
+        batch.fetch(want_pairs=True, pinned=True)   # page-locks the host buffers once (not part of a step)
         barrier()
         t1 = time.perf_counter()
         batch.run(costs, stream)
-        res = batch.fetch(want_pairs=True)   # synchronises, then copies score / flags / pair_off / pairs to the host
+        res = batch.fetch(want_pairs=True, pinned=True)   # synchronises, then copies score / flags / pair_off / pairs to the host
         dt = time.perf_counter() - t1
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if args.rehearse else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        res = _detach(res)   # the pinned buffers are reused by later fetches
         incl_d2h = {"value": round(cells_rank * world / dt / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt * 1e3, 3),
                     "d2h_ms": round(res.stats["ms_d2h"], 3), "d2h_bytes": int(res.pairs.nbytes + res.score.nbytes + res.flags.nbytes + res.pair_off.nbytes),
-                    "note": "one step + poa_batch_fetch (pageable host buffers), single shot"}
+                    "note": "one step + poa_batch_fetch into page-locked host buffers, single shot"}
     else:
         res = batch.fetch(want_pairs=(rank == 0))
 
@@ -290,6 +292,12 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _detach(res):
+    """Own copies of a BatchResult's arrays (ResidentBatch.fetch(pinned=True) hands out the batch's reusable buffers)."""
+    from poasta_amd import aligner
+    return aligner.BatchResult(res.score.copy(), res.pairs.copy(), res.pair_off.copy(), res.flags.copy(), res.stats)
 
 
 def _cpu_info():

@@ -272,17 +272,39 @@ class ResidentBatch:
         else:
             _lib.check(_lib.lib().poa_batch_run_ex(self.handle, C.byref(c), C.byref(config), C.c_void_p(stream or 0)))
 
-    def fetch(self, want_pairs=True):
+    def fetch(self, want_pairs=True, pinned=False):
+        """Synchronise and copy the results to the host.  pinned=True: the destination buffers are page-locked (allocated
+        once per batch through torch, if importable), which lets the device->host copy run at PCIe speed instead of through
+        the driver's staging of pageable memory."""
         n = self.n
-        score, flags = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
-        pair_off = np.zeros(n + 1, np.uint64)
-        pairs = np.zeros((max(self.pair_capacity, 1), 2), np.uint32) if want_pairs else None
+        bufs = self._host_buffers(want_pairs, pinned)
+        score, flags, pair_off, pairs = bufs
         st = _lib.PoaStats()
         _lib.check(_lib.lib().poa_batch_fetch(self.handle, _p(score), _p(pairs), _p(pair_off), self.pair_capacity,
                                               _p(flags), C.byref(st)))
         if want_pairs:
             pairs = pairs[:int(pair_off[n])]
         return BatchResult(score, pairs, pair_off, flags, st.as_dict())
+
+    def _host_buffers(self, want_pairs, pinned):
+        n = self.n
+        if pinned:
+            cached = getattr(self, "_pinned", None)
+            if cached is None:
+                try:
+                    import torch
+                    mk = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True).numpy()
+                    cached = (mk((n,), torch.int32).view(np.uint32), mk((n,), torch.int32).view(np.uint32),
+                              mk((n + 1,), torch.int64).view(np.uint64), mk((max(self.pair_capacity, 1), 2), torch.int32).view(np.uint32))
+                except Exception:
+                    cached = False
+                self._pinned = cached
+            if cached:
+                return cached[0], cached[1], cached[2], (cached[3] if want_pairs else None)
+        score, flags = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        pair_off = np.zeros(n + 1, np.uint64)
+        pairs = np.zeros((max(self.pair_capacity, 1), 2), np.uint32) if want_pairs else None
+        return score, flags, pair_off, pairs
 
     def stats(self):
         """Synchronise and return HIP-event timings summed over the runs since the last call."""
