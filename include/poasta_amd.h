@@ -226,6 +226,13 @@ int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** 
  * replayed search in the last exact / hybrid run, plus the number of steps the wave search took: out[4 * n], one
  * {num_queued, num_visited, num_pruned, steps} per query (zeros for queries that were not replayed). */
 int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out);
+/* how the dense pass of the last run stored its score planes: POA_LAYOUT_* bits.  Chosen per run from a bound on the optimal
+ * score (u32 Score values of the reference, src/aligner/scoring/mod.rs:64-70, are kept verbatim unless a narrower
+ * encoding is provably exact for everything the result depends on). */
+#define POA_LAYOUT_U16 1u       /* 2-byte cells (bound <= 65534) */
+#define POA_LAYOUT_COMPACT 2u   /* M plane + 4 flag bits per cell + the D rows that are read back */
+#define POA_LAYOUT_RELATIVE 4u  /* cells hold score - e * (shortest-path depth of the row - column): scores beyond u16 */
+int poa_batch_last_layout(poa_batch_t* b, uint32_t* layout);
 /* debugging / parity: copy the M, I, D score planes of query i (rows x (len+1), row = topological
  * rank, see poa_graph_node_rows) — only valid if the query's chunk was the last one run */
 int poa_batch_fetch_planes(poa_batch_t* b, uint32_t query, uint32_t* m, uint32_t* i, uint32_t* d);

@@ -21,7 +21,7 @@ FLAG_AMBIGUOUS, FLAG_START_QUIRK, FLAG_REF_PANIC, FLAG_SHORT_QUERY, FLAG_TRUNCAT
 EXPORTS = ["poa_version", "poa_last_error", "poa_device_count", "poa_graph_create", "poa_graph_destroy",
            "poa_graph_rows", "poa_graph_node_rows", "poa_align_batch", "poa_align_batch_ex", "poa_align_batch_2piece", "poa_planes_2piece", "poa_release_cache", "poa_batch_create", "poa_batch_run",
            "poa_batch_run_ex",
-           "poa_batch_fetch", "poa_batch_stats", "poa_batch_device_results", "poa_batch_fetch_search_counters", "poa_batch_fetch_planes", "poa_batch_destroy"]
+           "poa_batch_fetch", "poa_batch_stats", "poa_batch_device_results", "poa_batch_fetch_search_counters", "poa_batch_last_layout", "poa_batch_fetch_planes", "poa_batch_destroy"]
 
 
 class PoaCosts2(C.Structure):
@@ -124,6 +124,8 @@ def lib():
     L.poa_batch_stats.argtypes = [vp, C.POINTER(PoaStats)]
     L.poa_batch_fetch_search_counters.restype = C.c_int
     L.poa_batch_fetch_search_counters.argtypes = [vp, vp]
+    L.poa_batch_last_layout.restype = C.c_int
+    L.poa_batch_last_layout.argtypes = [vp, vp]
     L.poa_batch_device_results.restype = C.c_int
     L.poa_batch_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.poa_batch_fetch_planes.restype = C.c_int

@@ -318,6 +318,12 @@ class ResidentBatch:
         _lib.check(_lib.lib().poa_batch_fetch_search_counters(self.handle, _p(out)))
         return out
 
+    def layout(self):
+        """How the dense pass of the last run stored its planes: subset of {"u16", "compact", "relative"} (empty: u32 planes)."""
+        v = C.c_uint32(0)
+        _lib.check(_lib.lib().poa_batch_last_layout(self.handle, C.byref(v)))
+        return {name for bit, name in ((1, "u16"), (2, "compact"), (4, "relative")) if v.value & bit}
+
     def device_results(self):
         ptrs = [C.c_void_p() for _ in range(4)]
         _lib.check(_lib.lib().poa_batch_device_results(self.handle, *[C.byref(p) for p in ptrs]))

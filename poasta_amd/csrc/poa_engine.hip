@@ -191,6 +191,9 @@ struct poa_batch {
 
     DevBuf<RowMeta> d_rows;
     DevBuf<uint32_t> d_pred_rows;
+    DevBuf<uint32_t> d_row_depth, d_pred_k;   // depth potential of the relative u16 encoding (FlatGraph::row_depth / pred_k)
+    bool relative = false;                    // last run stored scores relative to that potential
+    bool dense_narrow = false, dense_compact = false, dense_relative = false;   // layout of the last run's dense pass (poa_batch_last_layout)
     DevBuf<uint8_t> d_qseq;
     DevBuf<uint64_t> d_qoff, d_scratch_off, d_pair_off;
     DevBuf<uint32_t> d_pitch, d_carry, d_score, d_flags, d_npairs;
@@ -414,6 +417,8 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     // device buffers
     HIP_TRY(b->d_rows.alloc(fg.rows.size()));
     HIP_TRY(b->d_pred_rows.alloc(std::max<size_t>(fg.pred_rows.size(), 1)));
+    HIP_TRY(b->d_pred_k.alloc(std::max<size_t>(fg.pred_k.size(), 1)));
+    HIP_TRY(b->d_row_depth.alloc(std::max<size_t>(fg.row_depth.size(), 1)));
     HIP_TRY(b->d_qseq.alloc(std::max<uint64_t>(qoff[n_queries], 1)));
     HIP_TRY(b->d_qoff.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_pitch.alloc(std::max<uint32_t>(n_queries, 1)));
@@ -440,6 +445,10 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(hipMemcpy(b->d_rows.p, fg.rows.data(), fg.rows.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
     if (!fg.pred_rows.empty())
         HIP_TRY(hipMemcpy(b->d_pred_rows.p, fg.pred_rows.data(), fg.pred_rows.size() * 4, hipMemcpyHostToDevice));
+    if (!fg.pred_k.empty())
+        HIP_TRY(hipMemcpy(b->d_pred_k.p, fg.pred_k.data(), fg.pred_k.size() * 4, hipMemcpyHostToDevice));
+    if (!fg.row_depth.empty())
+        HIP_TRY(hipMemcpy(b->d_row_depth.p, fg.row_depth.data(), fg.row_depth.size() * 4, hipMemcpyHostToDevice));
     if (qoff[n_queries]) HIP_TRY(hipMemcpy(b->d_qseq.p, qseq, qoff[n_queries], hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_qoff.p, qoff, ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_scratch_off.p, b->h_scratch_off.data(), ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
@@ -579,10 +588,26 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
     // compact layout (u16 only): 4-bit codes instead of the I plane, D rows only where they are read back.
     // POA_CFG_FULL_PLANES (or POA_COMPACT=0) keeps all three planes, e.g. for poa_batch_fetch_planes.
-    bool compact = narrow && !(cfg && (cfg->flags & POA_CFG_FULL_PLANES));
+    const bool want_full = cfg && (cfg->flags & POA_CFG_FULL_PLANES);
+    bool compact = narrow && !want_full;
     if (const char* cv = getenv("POA_COMPACT")) { if (atoi(cv) == 0) compact = false; }
     bool packed = true;  // packed-u16 arithmetic kernel for the compact layout (POA_PACKED=0: scalar u32 arithmetic)
     if (const char* pv2 = getenv("POA_PACKED")) packed = atoi(pv2) != 0;
+    // Scores beyond u16 (a read against a much longer graph, Global): store every cell relative to the depth potential
+    // e * (row_depth - column) (FlatGraph::row_depth).  All moves keep non-negative costs there, so the saturation argument
+    // above holds for the relative values, and the largest one on an optimal path is the end cell's:
+    //     S* - e * (shortest path nodes - L)  <=  ub - e * min_path_nodes + e * L  =  2 * (o + e * L).
+    // Only the pairs-across-quads kernels (compact layout) implement it; POA_RELATIVE=0 keeps u32 planes, =1 forces it
+    // wherever the bound allows (A-B against the absolute encodings).
+    const uint64_t rel_ub = 2 * ((uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * b->max_len);
+    bool relative = !narrow && rel_ub <= 65534 && !want_full && packed && !getenv("POA_PLANES") && !getenv("POA_COMPACT");
+    if (const char* rv = getenv("POA_RELATIVE")) {
+        if (atoi(rv) == 0) relative = false;
+        else relative = rel_ub <= 65534 && !want_full && packed;
+    }
+    if (relative) { narrow = true; compact = true; }
+    b->relative = relative;
+    b->dense_narrow = narrow; b->dense_compact = compact; b->dense_relative = relative;
     b->narrow = narrow;
     b->compact = compact;
     // 2-byte elements let twice the queries share the workspace; the exact replay needs the u32 plan
@@ -630,12 +655,20 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         tp.cost_x = costs->mismatch; tp.cost_o = costs->gap_open; tp.cost_e = costs->gap_extend;
         tp.spec_depth = spec_depth;
         tp.exact_pass = 0; tp.ex_status = nullptr; tp.ex_end = nullptr; tp.code_fmt = 0;
+        tp.row_depth = relative ? b->d_row_depth.p : nullptr;
         FwdParams fp;
         fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
         fp.first_query = ch.first; fp.n_queries = ch.count;
         fp.qseq = b->d_qseq.p; fp.qoff = b->d_qoff.p; fp.pitch = b->d_pitch.p; fp.plane_off = PL.d_off.p;
         fp.planes = b->d_planes.p; fp.strip_carry = b->d_carry.p;
         fp.cost_x = costs->mismatch; fp.cost_oe = (uint32_t)costs->gap_open + costs->gap_extend; fp.cost_e = costs->gap_extend;
+        // the same recurrences under the depth potential: deletions lose the e the potential already charges per row,
+        // insertions pay it twice, every predecessor edge adds e * pred_k
+        fp.cost_de = relative ? 0u : fp.cost_e;
+        fp.cost_doe = relative ? (uint32_t)costs->gap_open : fp.cost_oe;
+        fp.cost_ie = relative ? 2u * fp.cost_e : fp.cost_e;
+        fp.cost_ioe = relative ? fp.cost_oe + fp.cost_e : fp.cost_oe;
+        fp.pred_k = relative ? b->d_pred_k.p : nullptr;
         fp.pipeline_error = b->d_pipeline_error.p;
         const uint32_t blocks = (ch.count + 3) / 4;
 #define LAUNCH_FWD(QQ, TT)                                                                                              \
@@ -649,20 +682,21 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         if (narrow) {
             uint32_t quads = max_pitch <= 512 ? 1 : 2;  // 512 columns per quad (8 x u16 per lane)
             if (quads_override == 1 || quads_override == 2) quads = (uint32_t)quads_override;
+            if (relative) quads = 2;  // the relative encoding lives in the pairs-across-quads kernels only
             if (compact && packed) {
                 // queries longer than one strip: one workgroup per query, its strips pipelined over the waves (MW)
                 bool mw = max_pitch > 512 * quads;
-                if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
-                bool px = max_pitch <= 1024 && quads == 2 && !fuse_tb;  // one strip of up to 1024 columns: the pairs-across-quads kernel
-                if (const char* xv = getenv("POA_PX")) px = px && atoi(xv) != 0;
+                if (const char* mv = getenv("POA_MW")) mw = mw && (atoi(mv) != 0 || relative);
+                bool px = max_pitch <= 1024 && quads == 2 && (!fuse_tb || relative);  // one strip of up to 1024 columns: the pairs-across-quads kernel
+                if (const char* xv = getenv("POA_PX")) px = (px && atoi(xv) != 0) || (px && relative);
                 if (px) {
                     // scores below 0x3FFF (same bound as for u16, one power lower): two flags ride in the stored M value
-                    bool mf = ub <= 16382;
+                    bool mf = ub <= 16382 && !relative;
                     if (const char* fv2 = getenv("POA_MF")) mf = mf && atoi(fv2) != 0;
                     tp.code_fmt = mf ? 2u : 1u;
                     if (mf) hipLaunchKernelGGL(poa_forward_px_kernel<true>, dim3(blocks), dim3(256), 0, stream, fp);
                     else hipLaunchKernelGGL(poa_forward_px_kernel<false>, dim3(blocks), dim3(256), 0, stream, fp);
-                } else if (mw && pxmw_ok(ch.count, max_pitch)) {
+                } else if (mw && (relative || pxmw_ok(ch.count, max_pitch))) {
                     // pairs-across-quads mapping, 1024-column strips pipelined over the waves of a workgroup
                     tp.code_fmt = 1;
                     const uint32_t waves = mw_waves((max_pitch + 1023) / 1024);
@@ -715,7 +749,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
-        if (!(fuse_tb && max_pitch <= 1024 && (!compact || packed))) {
+        if (!(fuse_tb && !relative && max_pitch <= 1024 && (!compact || packed))) {
             // four walks per wave only when one walk per wave would exceed the chip's wave slots (256 CUs x 32)
             const int tbg = (getenv("POA_TB_GROUP") || ch.count > 8192) ? tb_group : 64;
             if (compact && tbg == 16) {
@@ -878,10 +912,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             hipLaunchKernelGGL(poa_exact_kernel, dim3((ch.count + per_block - 1) / per_block), dim3(EXACT_BLOCK), lds_graph ? lds_bytes : 0, stream, ep);
             }
             HIP_TRY(hipGetLastError());
-            tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p; tp.ex_end = b->d_ex_end.p;
+            tp.exact_pass = 1; tp.ex_status = b->d_ex_status.p; tp.ex_end = b->d_ex_end.p; tp.row_depth = nullptr;
             hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             HIP_TRY(hipGetLastError());
-            b->narrow = false; b->compact = false;  // the planes now hold the replayed u32 table
+            b->narrow = false; b->compact = false; b->relative = false;  // the planes now hold the replayed u32 table
         }
         HIP_TRY(hipEventRecord(events[ev++], stream));
     }
@@ -988,6 +1022,13 @@ int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** 
     if (flags) *flags = b->d_flags.p;
     if (pair_off) *pair_off = b->d_pair_off.p;
     if (pairs) *pairs = b->d_pairs.p;
+    return POA_OK;
+}
+
+int poa_batch_last_layout(poa_batch_t* b, uint32_t* layout) {
+    if (!b || !layout) return fail(POA_ERR_INVALID_ARG, "poa_batch_last_layout: null argument");
+    if (!b->ran) return fail(POA_ERR_INVALID_ARG, "poa_batch_last_layout: poa_batch_run has not been called");
+    *layout = (b->dense_narrow ? POA_LAYOUT_U16 : 0u) | (b->dense_compact ? POA_LAYOUT_COMPACT : 0u) | (b->dense_relative ? POA_LAYOUT_RELATIVE : 0u);
     return POA_OK;
 }
 

@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
     uint16_t* __restrict__ Ip = Mp + RP;  // holds the flag bit-planes
     uint16_t* __restrict__ Dp = Ip + RP;
-    const uint32_t e = P.cost_e, oe = P.cost_oe, x = P.cost_x;
-    const uint32_t e2 = e | (e << 16), oe2 = oe | (oe << 16), x2 = x | (x << 16);
+    // deletion and insertion costs apart (they differ under the relative encoding, FwdParams::cost_de ..); the end row's
+    // deletion always costs the plain e
+    const uint32_t e = P.cost_ie, x = P.cost_x;
+    const uint32_t e2 = e | (e << 16), ioe2 = P.cost_ioe | (P.cost_ioe << 16), x2 = x | (x << 16);
+    const uint32_t de2 = P.cost_de | (P.cost_de << 16), doe2 = P.cost_doe | (P.cost_doe << 16), eend2 = P.cost_e | (P.cost_e << 16);
     auto pack16 = [](uint32_t v) { v = v < I16 ? v : I16; return v | (v << 16); };
     const uint32_t step = K * e;
     const uint32_t step2 = pack16(step);
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     // waiting for it (vmcnt) also waits for every plane store of the previous row.
     const CRowWords* crows = (const CRowWords*)P.rows;
     const CU32* cpred = (const CU32*)P.pred_rows;
+    const CU32* cpredk = (const CU32*)P.pred_k;  // relative encoding: e * pred_k is added to what a predecessor hands over
 
     // predecessor minima of the last multi-predecessor row: sibling rows (ROW_SAME_PREDS) reuse them
     uint32_t PMc[K], PDc[K], PMlc = INF2;
@@ -133,8 +137,9 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             uint32_t (&Mc)[K] = Mout;
             uint32_t (&Dc)[K] = Dout;
             uint32_t Ic[K], PDe[K];
+            const uint32_t de_row2 = (meta.flags & ROW_END) ? eend2 : de2;
 #pragma unroll
-            for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], e2);
+            for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], de_row2);
             if (meta.flags & ROW_END) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -175,13 +180,13 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     // D: open a deletion only where the symbols differ (or past the query end, where q is 0)
-                    Dc[k] = pk_min(PDe[k], pk_max(pk_add_sat(PM[k], oe2), mD[k]));
+                    Dc[k] = pk_min(PDe[k], pk_max(pk_add_sat(PM[k], doe2), mD[k]));
                     Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
                     if (k == 0) Hc[k] &= start_keep;  // H[start][0] = 0
                     pm_left = PM[k];
                     cost_left = pk_sub_sat(x2, mD[k]);
                     // insertion open: A = (q != child symbol) ? H + oe : INF
-                    const uint32_t a = pk_max(pk_add_sat(Hc[k], oe2), mI[k]);
+                    const uint32_t a = pk_max(pk_add_sat(Hc[k], ioe2), mI[k]);
                     Ic[k] = t;
                     t = pk_min(pk_add_sat(t, e2), a);
                 }
@@ -284,6 +289,13 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                         }
                     }
                 }
+                if (!MF && cpredk) {
+                    const uint32_t ex2 = pack16(cpredk[meta.pred_begin + pe] * P.cost_e);
+                    if (ex2) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { tm[k] = pk_add_sat(tm[k], ex2); td[k] = pk_add_sat(td[k], ex2); }
+                    }
+                }
                 PMl = pk_min(PMl, shr_lane(tm[K - 1]));
 #pragma unroll
                 for (int k = 0; k < K; ++k) { PM[k] = pk_min(PM[k], tm[k]); PD[k] = pk_min(PD[k], td[k]); }
@@ -335,8 +347,9 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
     uint16_t* __restrict__ Ip = Mp + RP;
     uint16_t* __restrict__ Dp = Ip + RP;
     uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;
-    const uint32_t e = P.cost_e, oe = P.cost_oe, x = P.cost_x;
-    const uint32_t e2 = e | (e << 16), oe2 = oe | (oe << 16), x2 = x | (x << 16);
+    const uint32_t e = P.cost_ie, x = P.cost_x;   // see poa_forward_px_kernel
+    const uint32_t e2 = e | (e << 16), ioe2 = P.cost_ioe | (P.cost_ioe << 16), x2 = x | (x << 16);
+    const uint32_t de2 = P.cost_de | (P.cost_de << 16), doe2 = P.cost_doe | (P.cost_doe << 16), eend2 = P.cost_e | (P.cost_e << 16);
     auto pack16 = [](uint32_t v) { v = v < I16 ? v : I16; return v | (v << 16); };
     auto clamp16 = [](uint32_t v) { return v < I16 ? v : I16; };
     const uint32_t step = K * e;
@@ -348,6 +361,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
     const uint32_t n_groups = (n_strips + S - 1) / S;
     const CRowWords* crows = (const CRowWords*)P.rows;
     const CU32* cpred = (const CU32*)P.pred_rows;
+    const CU32* cpredk = (const CU32*)P.pred_k;  // relative encoding: e * pred_k is added to what a predecessor hands over
 
     for (uint32_t g = 0; g < n_groups; ++g) {
         const uint32_t s = g * S + wave;
@@ -401,8 +415,9 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                 uint32_t (&Mc)[K] = Mout;
                 uint32_t (&Dc)[K] = Dout;
                 uint32_t Ic[K], PDe[K];
+                const uint32_t de_row2 = (meta.flags & ROW_END) ? eend2 : de2;
 #pragma unroll
-                for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], e2);
+                for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], de_row2);
                 if (meta.flags & ROW_END) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
@@ -421,12 +436,12 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const uint32_t eq1 = pk_is_zero(qP[k] ^ sym2);
-                        Dc[k] = pk_min(PDe[k], pk_inf_where(pk_add_sat(PM[k], oe2), eq1));
+                        Dc[k] = pk_min(PDe[k], pk_inf_where(pk_add_sat(PM[k], doe2), eq1));
                         Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
                         if (k == 0) Hc[k] &= start_keep;
                         pm_left = PM[k];
                         cost_left = pk_sub_sat(x2, pk_shl<8>(eq1));
-                        const uint32_t a = pk_inf_where(pk_add_sat(Hc[k], oe2), pk_is_zero(qP[k] ^ csym2));
+                        const uint32_t a = pk_inf_where(pk_add_sat(Hc[k], ioe2), pk_is_zero(qP[k] ^ csym2));
                         Ic[k] = t;
                         t = pk_min(pk_add_sat(t, e2), a);
                     }
@@ -528,6 +543,15 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                     uint32_t edge = I16;
                     if (from_ring && r - pr <= ROW_NEAR) edge = mw_ring[wave - 1][(prog_base + pr) % MW_RING][2];
                     else if (s > 0) edge = (uint32_t)Mp[(uint64_t)pr * pitch + sbase - 1];
+                    if (cpredk) {
+                        const uint32_t ex = clamp16(cpredk[meta.pred_begin + pe] * P.cost_e);
+                        if (ex) {
+                            const uint32_t ex2 = ex | (ex << 16);
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { tm[k] = pk_add_sat(tm[k], ex2); td[k] = pk_add_sat(td[k], ex2); }
+                            edge = clamp16((edge & 0xFFFFu) + ex);
+                        }
+                    }
                     PMl = pk_min(PMl, shr_lane(tm[K - 1], edge));
 #pragma unroll
                     for (int k = 0; k < K; ++k) { PM[k] = pk_min(PM[k], tm[k]); PD[k] = pk_min(PD[k], td[k]); }

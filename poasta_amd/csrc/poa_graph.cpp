@@ -169,6 +169,21 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
             }
         }
         g.min_path_nodes = (dist[g.end_row] == 0xFFFFFFFFu || dist[g.end_row] == 0) ? 0 : dist[g.end_row] - 1;
+        // depth potential (see FlatGraph::row_depth): d(v) = 1 + min over predecessors; the end row consumes no query
+        // symbol, so it sits at the depth of its shallowest predecessor
+        g.row_depth.assign(n, 0);
+        for (uint32_t r = 0; r < n; ++r) g.row_depth[r] = dist[r] == 0xFFFFFFFFu ? 0u : dist[r];
+        if (dist[g.end_row] != 0xFFFFFFFFu && dist[g.end_row] > 0) g.row_depth[g.end_row] = dist[g.end_row] - 1;
+        g.pred_k.assign(g.pred_rows.size(), 0);
+        for (uint32_t r = 0; r < n; ++r) {
+            const RowMeta& m = g.rows[r];
+            if (dist[r] == 0xFFFFFFFFu) continue;
+            for (uint32_t pe = 0; pe < m.pred_count; ++pe) {
+                const uint32_t pr = g.pred_rows[m.pred_begin + pe];
+                if (dist[pr] == 0xFFFFFFFFu) continue;  // an unreachable predecessor holds INF everywhere
+                g.pred_k[m.pred_begin + pe] = g.row_depth[pr] + ((m.flags & ROW_END) ? 0u : 1u) - g.row_depth[r];
+            }
+        }
     }
     // shortest path to the end row, in edges (what the reference's dist_to_end BFS finds, gap_affine.rs:91-119)
     g.sp_to_end.assign(n, 0xFFFFFFFFu);

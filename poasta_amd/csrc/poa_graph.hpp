@@ -70,6 +70,13 @@ struct FlatGraph {
     uint32_t max_indegree = 0;
     uint32_t min_path_nodes = 0;         // real nodes on the shortest start -> end path
     std::vector<uint32_t> sp_to_end;     // row -> edges on the shortest path to the end row (0xFFFFFFFF: none)
+    // Depth potential for the relative u16 encoding: row_depth[r] = nodes on the shortest start -> r path.
+    // A cell is stored as  score - e * row_depth[r] + e * column  (>= 0: reaching row r costs at least e per node that is not
+    // matched to a query symbol), under which every move keeps a non-negative cost: the deletion extension becomes
+    // e * pred_k, the (mis)match x * [differs] + e * pred_k, the insertion extension 2e, where
+    // pred_k[edge p -> r] = 1 + row_depth[p] - row_depth[r] >= 0 (0 along every shortest path, in particular for chain rows).
+    std::vector<uint32_t> row_depth;     // [n]
+    std::vector<uint32_t> pred_k;        // [pred_rows.size()]
 
     // ---- exact-replay mode only: the reference's per-graph preprocessing --------------------
     // successors as rows, trait order preserved (DFA / expand_all iterate them in this order)

@@ -50,6 +50,11 @@ struct FwdParams {
     uint32_t* planes;           // workspace: per query [M | I | D], each n_rows * pitch
     uint32_t* strip_carry;      // [n_queries_in_chunk * n_rows] I carried between strips (long queries)
     uint32_t cost_x, cost_oe, cost_e;
+    // pairs-across-quads kernels: deletion / insertion costs apart, and e * pred_k[edge] added to every predecessor value
+    // (relative encoding, FlatGraph::row_depth); absolute encoding: cost_de = cost_ie = cost_e, cost_doe = cost_ioe = cost_oe,
+    // pred_k = nullptr.  The end row's deletion always costs cost_e.
+    uint32_t cost_de, cost_doe, cost_ie, cost_ioe;
+    const uint32_t* pred_k;     // [n_edges] or nullptr
     uint32_t* pipeline_error;   // one word: set when a wave of the multi-wave pipeline gave up waiting (a protocol bug, not an input)
 };
 
@@ -77,6 +82,7 @@ struct TbParams {
     const uint32_t* ex_end;       // [2 * total] (row, offset) of the end cell the replayed search stopped at
     uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel<false>),
                                   // 2 = flags A, C in bits 14, 15 of the stored M value, B, D as bit-planes (poa_forward_px_kernel<true>)
+    const uint32_t* row_depth;    // relative encoding: stored value = score - e * (row_depth[row] - column); nullptr: absolute
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -162,6 +168,7 @@ struct TbCtx {
     const uint8_t* q;
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
+    const uint32_t* row_depth;  // relative encoding (TbParams::row_depth) or nullptr
 };
 
 struct TbStep {
@@ -194,15 +201,29 @@ template <typename T>
 __device__ __forceinline__ uint32_t pl_tiled(const TbCtx<T>& c, uint32_t row, uint32_t j, uint32_t st) {
     return reinterpret_cast<const uint32_t*>(c.M)[ex_cell_index(row, j, st, c.n_rows, c.pitch)];  // st: 0 M, 1 D, 2 I
 }
+// relative encoding -> the score itself: + e * (row_depth[row] - column), in wrapping u32 arithmetic (the sum is >= 0)
+template <typename T>
+__device__ __forceinline__ uint32_t tb_abs(const TbCtx<T>& c, uint32_t v, uint32_t depth, uint32_t j) {
+    return v == INF ? INF : v + c.e * depth - c.e * j;
+}
 template <typename T>
 __device__ __forceinline__ uint32_t plM(const TbCtx<T>& c, uint32_t row, uint32_t j) {
     if (c.tiled) return pl_tiled(c, row, j, 0);
     if (c.code_fmt == 2) return mf_value((uint32_t)c.M[(uint64_t)row * c.pitch + j]);
+    if (c.row_depth) {
+        const uint32_t depth = c.row_depth[row];  // independent of the plane load: one round trip for both
+        return tb_abs(c, PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j), depth, j);
+    }
     return PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j);
 }
 template <typename T>
 __device__ __forceinline__ uint32_t plD(const TbCtx<T>& c, uint32_t row, uint32_t j) {
-    return c.tiled ? pl_tiled(c, row, j, 1) : PlaneIO<T>::get(c.D + (uint64_t)row * c.pitch + j);
+    if (c.tiled) return pl_tiled(c, row, j, 1);
+    if (c.row_depth) {
+        const uint32_t depth = c.row_depth[row];
+        return tb_abs(c, PlaneIO<T>::get(c.D + (uint64_t)row * c.pitch + j), depth, j);
+    }
+    return PlaneIO<T>::get(c.D + (uint64_t)row * c.pitch + j);
 }
 template <typename T>
 __device__ __forceinline__ uint32_t plI(const TbCtx<T>& c, uint32_t row, uint32_t j) {
@@ -373,6 +394,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     c.n_rows = P.n_rows;
     c.start_row = P.start_row; c.end_row = P.end_row;
     c.x = P.cost_x; c.o = P.cost_o; c.e = P.cost_e;
+    c.row_depth = P.row_depth;
     const uint32_t L = c.L;
 
     uint2* out = P.scratch + P.scratch_off[qi];

@@ -1,0 +1,159 @@
+"""Scores beyond u16 in 2-byte cells: the relative encoding (cells hold score - e * (shortest-path depth of the row - column),
+DESIGN.md §5) against the u32 planes, which keep the reference's `Score` values verbatim (src/aligner/scoring/mod.rs:64-70),
+and against the oracle.  Bit-exact: scores, (rpos, qpos) pairs and flags."""
+import os
+
+import numpy as np
+import pytest
+
+from poasta_amd import workloads as W
+from poasta_amd.graph import GraphBuilder, pack_queries
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def _costs(engine, m=4, o=6, e=2):
+    return engine.GapAffine(m, e, o)
+
+
+def _long_bubbly_graph(seed, n_backbone, n_bypass=9, n_branch=60, n_snp=400, two_ends=True):
+    """A chain of n_backbone nodes with SNP bubbles, inserted branches (longer than what they replace, so the row order and
+    the shortest-path depth part ways: pred_k > 0 where they rejoin) and bypass edges that skip up to 400 nodes, one of
+    them 2 500 (few enough that the shortest start -> end path stays long: the bound on the score is taken along it)."""
+    rng = np.random.default_rng(seed)
+    b = GraphBuilder()
+    sym = ACGT[rng.integers(0, 4, n_backbone)]
+    ids = [b.add_node(int(s)) for s in sym]
+    for i in range(n_backbone - 1):
+        b.add_edge(ids[i], ids[i + 1])
+    for i in rng.choice(np.arange(1, n_backbone - 1), n_snp, replace=False):
+        alt = b.add_node(int(ACGT[(int(np.where(ACGT == sym[i])[0][0]) + 1 + int(rng.integers(0, 3))) % 4]))
+        b.add_edge(ids[i - 1], alt)
+        b.add_edge(alt, ids[i + 1])
+    for k in range(n_bypass):
+        a = int(rng.integers(0, n_backbone - 20))
+        c = min(n_backbone - 1, a + 2 + (2500 if k == 0 else int(rng.integers(0, 400))))
+        b.add_edge(ids[a], ids[c])
+    for _ in range(n_branch):
+        a = int(rng.integers(0, n_backbone - 60))
+        skip = int(rng.integers(1, 40))
+        length = skip + int(rng.integers(1, 80))          # the branch is longer than the stretch it replaces
+        prev = ids[a]
+        for s in ACGT[rng.integers(0, 4, length)]:
+            v = b.add_node(int(s))
+            b.add_edge(prev, v)
+            prev = v
+        b.add_edge(prev, ids[a + skip + 1])
+    if two_ends:
+        # a second way out: the end row gets two predecessors of different depth
+        a = ids[n_backbone - 300]
+        prev = a
+        for s in ACGT[rng.integers(0, 4, 25)]:
+            v = b.add_node(int(s))
+            b.add_edge(prev, v)
+            prev = v
+    return b.finish(), sym
+
+
+def _window_queries(seed, sym, n, lo, hi):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi))
+        a = int(rng.integers(0, len(sym) - L))
+        out.append(W.mutate(rng, sym[a:a + L].copy(), 0.05, 0.03, 0.03))
+    # edge cases: the empty query, one base, a query of pure noise
+    out += [np.zeros(0, np.uint8), sym[5:6].copy(), ACGT[rng.integers(0, 4, 333)]]
+    return out
+
+
+def _run(engine, g, qseq, qoff, env, costs=(4, 6, 2), config=None):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        rb = engine.ResidentBatch(g, qseq, qoff)
+        rb.run(_costs(engine, *costs), None, config)
+        res = rb.fetch()
+        layout = rb.layout()
+        rb.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    return res, layout
+
+
+def _same(a, b):
+    assert np.array_equal(a.score, b.score)
+    assert np.array_equal(a.flags, b.flags)
+    assert np.array_equal(a.pair_off, b.pair_off)
+    assert np.array_equal(a.pairs, b.pairs)
+
+
+@pytest.mark.parametrize("seed,lo,hi", [(1, 40, 900), (2, 900, 1024), (3, 1030, 3000)])
+def test_relative_equals_u32_planes(engine, oracle, seed, lo, hi):
+    """One strip (poa_forward_px_kernel) and several (poa_forward_pxmw_kernel): default = relative u16, POA_PLANES=32 = u32."""
+    g, sym = _long_bubbly_graph(seed, 40000)
+    qs = _window_queries(seed + 10, sym, 21, lo, hi)
+    qseq, qoff = pack_queries(qs)
+    rel, layout = _run(engine, g, qseq, qoff, {})
+    assert layout == {"u16", "compact", "relative"}
+    assert int(rel.score[:21].min()) > 65534          # no absolute 2-byte encoding could hold these
+    u32, layout32 = _run(engine, g, qseq, qoff, {"POA_PLANES": "32"})
+    assert layout32 == set()
+    _same(rel, u32)
+    # and the oracle's dense tables for a few members (scores, alignments, certificate flags)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    idx = [0, 7, 20, 21, 22, 23]
+    sub = [qs[i] for i in idx]
+    sq, so = pack_queries(sub)
+    D = og.dense_batch(sq, so, oracle.Costs(4, 6, 2), threads=6)
+    for k, i in enumerate(idx):
+        assert int(rel.score[i]) == int(D["score"][k])
+        assert rel.raw_alignment(i) == oracle.batch_alignment(D, k)
+        assert int(rel.flags[i]) == int(D["flags"][k])
+
+
+def test_relative_with_other_costs_and_the_msa_graph(engine):
+    """configs[3]-shaped graph (MSA columns: sibling rows that share their predecessors, ROW_SAME_PREDS) and gap-extend 1 / 3."""
+    g, (qseq, qoff) = W.config4(n_queries=12, ref_len=34000, n_hap=12, length=2500)
+    for costs in ((4, 6, 2), (3, 5, 1), (7, 2, 3)):
+        rel, layout = _run(engine, g, qseq, qoff, {"POA_RELATIVE": "1"}, costs)   # (with e = 1 the absolute bound would still fit)
+        assert "relative" in layout, costs
+        u32, _ = _run(engine, g, qseq, qoff, {"POA_PLANES": "32"}, costs)
+        _same(rel, u32)
+
+
+def test_relative_hybrid_is_the_reference(engine, oracle):
+    """Hybrid mode on top of a relative dense pass: the replay takes its order and its flags from that pass."""
+    g, sym = _long_bubbly_graph(5, 38000, n_bypass=4, n_branch=20, n_snp=200, two_ends=False)
+    qs = _window_queries(55, sym, 6, 200, 700)[:6]
+    qseq, qoff = pack_queries(qs)
+    res, layout = _run(engine, g, qseq, qoff, {}, config=engine.make_config("hybrid"))
+    assert "relative" in layout
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=6)
+    for i in range(len(qs)):
+        assert A["status"][i] == 0
+        assert int(res.score[i]) == int(A["score"][i])
+        assert res.raw_alignment(i) == oracle.batch_alignment(A, i)
+
+
+def test_bound_decides_the_layout(engine):
+    """Absolute u16 while the bound on the optimal score allows, relative while 2 (o + e L) does, else u32."""
+    g, sym = _long_bubbly_graph(9, 33000, n_bypass=0, n_branch=0, n_snp=0, two_ends=False)
+    short = pack_queries([sym[100:400].copy()])
+    long_ = pack_queries([ACGT[np.random.default_rng(1).integers(0, 4, 17000)]])
+    assert _run(engine, g, *short, {})[1] == {"u16", "compact", "relative"}
+    assert _run(engine, g, *long_, {})[1] == set()               # 2 * (6 + 2 * 17000) > 65534
+    assert _run(engine, g, *short, {"POA_RELATIVE": "0"})[1] == set()
+    gs, sym2 = _long_bubbly_graph(9, 3000, n_bypass=0, n_branch=0, n_snp=0, two_ends=False)
+    assert _run(engine, gs, *pack_queries([sym2[100:400].copy()]), {})[1] == {"u16", "compact"}
+    a, _ = _run(engine, gs, *pack_queries([sym2[100:400].copy()]), {})
+    b, lay = _run(engine, gs, *pack_queries([sym2[100:400].copy()]), {"POA_RELATIVE": "1"})
+    assert "relative" in lay
+    _same(a, b)
