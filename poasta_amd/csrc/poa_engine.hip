@@ -173,15 +173,16 @@ struct poa_batch {
     std::vector<uint64_t> h_scratch_off;
     struct Chunk { uint32_t first, count; };
     // How the queries share the plane workspace.  plan[0]: 4-byte elements (u32 planes, exact replay);
-    // plan[1]: 2-byte elements (u16 / compact layouts) — twice the queries per chunk when the batch needs chunks.
+    // plan[1]: 2-byte elements, three full planes (POA_CFG_FULL_PLANES with u16 scores) — twice the queries per chunk when
+    // the batch needs chunks; plan[2]: the compact layout at its real size (compact_plane_elems, ~2.7 bytes per cell).
     struct Plan {
         std::vector<Chunk> chunks;
         std::vector<uint64_t> off;   // per query: offset of its planes in ELEMENTS of the layout's type
         uint32_t max_chunk = 0;
         DevBuf<uint64_t> d_off;
     };
-    Plan plan[2];
-    bool plan16_same = true;         // plan[1] not built: everything fits in one chunk anyway
+    Plan plan[3];
+    bool plan16_same = true;         // plan[1], plan[2] not built: everything fits in one chunk anyway
     int active_plan = 0;             // plan of the last run
     const Plan& cur() const { return plan[active_plan]; }
     uint64_t max_len = 0;
@@ -192,6 +193,7 @@ struct poa_batch {
     DevBuf<RowMeta> d_rows;
     DevBuf<uint32_t> d_pred_rows;
     DevBuf<uint32_t> d_row_depth, d_pred_k;   // depth potential of the relative u16 encoding (FlatGraph::row_depth / pred_k)
+    DevBuf<uint32_t> d_dslot, d_pred_dslot;   // compact layout: slots of the kept D rows (FlatGraph::d_slot / pred_dslot)
     bool relative = false;                    // last run stored scores relative to that potential
     bool dense_narrow = false, dense_compact = false, dense_relative = false;   // layout of the last run's dense pass (poa_batch_last_layout)
     DevBuf<uint8_t> d_qseq;
@@ -392,12 +394,12 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
         }
     }
     // greedy chunking, once per element size
-    auto make_plan = [&](poa_batch::Plan& pl, uint64_t elem_bytes) {
+    auto make_plan = [&](poa_batch::Plan& pl, uint64_t elem_bytes, bool compact_size) {
         pl.off.resize(n_queries);
         uint32_t first = 0;
         uint64_t used = 0;
         for (uint32_t i = 0; i < n_queries; ++i) {
-            const uint64_t need = q_plane_elems[i] * elem_bytes;
+            const uint64_t need = (compact_size ? compact_plane_elems(rows, b->h_pitch[i], fg.n_store_d) : q_plane_elems[i]) * elem_bytes;
             if (used + need > ws && i > first) {
                 pl.chunks.push_back({first, i - first});
                 first = i; used = 0;
@@ -408,10 +410,10 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
         if (n_queries > first) pl.chunks.push_back({first, n_queries - first});
         for (auto& c : pl.chunks) pl.max_chunk = std::max(pl.max_chunk, c.count);
     };
-    make_plan(b->plan[0], 4);
+    make_plan(b->plan[0], 4, false);
     b->plan16_same = b->plan[0].chunks.size() <= 1;
-    if (!b->plan16_same) make_plan(b->plan[1], 2);
-    const uint32_t max_chunk_any = std::max(b->plan[0].max_chunk, b->plan[1].max_chunk);
+    if (!b->plan16_same) { make_plan(b->plan[1], 2, false); make_plan(b->plan[2], 2, true); }
+    const uint32_t max_chunk_any = std::max(b->plan[0].max_chunk, std::max(b->plan[1].max_chunk, b->plan[2].max_chunk));
     b->cols_per_lane = 16;
 
     // device buffers
@@ -419,10 +421,12 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
     HIP_TRY(b->d_pred_rows.alloc(std::max<size_t>(fg.pred_rows.size(), 1)));
     HIP_TRY(b->d_pred_k.alloc(std::max<size_t>(fg.pred_k.size(), 1)));
     HIP_TRY(b->d_row_depth.alloc(std::max<size_t>(fg.row_depth.size(), 1)));
+    HIP_TRY(b->d_dslot.alloc(std::max<size_t>(fg.d_slot.size(), 1)));
+    HIP_TRY(b->d_pred_dslot.alloc(std::max<size_t>(fg.pred_dslot.size(), 1)));
     HIP_TRY(b->d_qseq.alloc(std::max<uint64_t>(qoff[n_queries], 1)));
     HIP_TRY(b->d_qoff.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_pitch.alloc(std::max<uint32_t>(n_queries, 1)));
-    for (int k = 0; k < (b->plan16_same ? 1 : 2); ++k) HIP_TRY(b->plan[k].d_off.alloc(std::max<uint32_t>(n_queries, 1)));
+    for (int k = 0; k < (b->plan16_same ? 1 : 3); ++k) HIP_TRY(b->plan[k].d_off.alloc(std::max<uint32_t>(n_queries, 1)));
     HIP_TRY(b->d_scratch_off.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_pair_off.alloc((size_t)n_queries + 1));
     HIP_TRY(b->d_score.alloc(std::max<uint32_t>(n_queries, 1)));
@@ -449,12 +453,16 @@ int poa_batch_create(const poa_graph_t* g, int device, uint32_t n_queries, const
         HIP_TRY(hipMemcpy(b->d_pred_k.p, fg.pred_k.data(), fg.pred_k.size() * 4, hipMemcpyHostToDevice));
     if (!fg.row_depth.empty())
         HIP_TRY(hipMemcpy(b->d_row_depth.p, fg.row_depth.data(), fg.row_depth.size() * 4, hipMemcpyHostToDevice));
+    if (!fg.d_slot.empty())
+        HIP_TRY(hipMemcpy(b->d_dslot.p, fg.d_slot.data(), fg.d_slot.size() * 4, hipMemcpyHostToDevice));
+    if (!fg.pred_dslot.empty())
+        HIP_TRY(hipMemcpy(b->d_pred_dslot.p, fg.pred_dslot.data(), fg.pred_dslot.size() * 4, hipMemcpyHostToDevice));
     if (qoff[n_queries]) HIP_TRY(hipMemcpy(b->d_qseq.p, qseq, qoff[n_queries], hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_qoff.p, qoff, ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_scratch_off.p, b->h_scratch_off.data(), ((size_t)n_queries + 1) * 8, hipMemcpyHostToDevice));
     if (n_queries) {
         HIP_TRY(hipMemcpy(b->d_pitch.p, b->h_pitch.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice));
-        for (int k = 0; k < (b->plan16_same ? 1 : 2); ++k)
+        for (int k = 0; k < (b->plan16_same ? 1 : 3); ++k)
             HIP_TRY(hipMemcpy(b->plan[k].d_off.p, b->plan[k].off.data(), (size_t)n_queries * 8, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
@@ -611,7 +619,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     b->narrow = narrow;
     b->compact = compact;
     // 2-byte elements let twice the queries share the workspace; the exact replay needs the u32 plan
-    b->active_plan = (narrow && mode == POA_MODE_DENSE && !b->plan16_same) ? 1 : 0;
+    b->active_plan = (narrow && mode == POA_MODE_DENSE && !b->plan16_same) ? (compact ? 2 : 1) : 0;
     const poa_batch::Plan& PL = b->cur();
     std::vector<hipEvent_t> events;
     const size_t n_events = 2 + 3 * PL.chunks.size();
@@ -656,6 +664,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         tp.spec_depth = spec_depth;
         tp.exact_pass = 0; tp.ex_status = nullptr; tp.ex_end = nullptr; tp.code_fmt = 0;
         tp.row_depth = relative ? b->d_row_depth.p : nullptr;
+        tp.d_slot = b->d_dslot.p; tp.pred_dslot = b->d_pred_dslot.p;
         FwdParams fp;
         fp.rows = b->d_rows.p; fp.pred_rows = b->d_pred_rows.p; fp.n_rows = fg.n;
         fp.first_query = ch.first; fp.n_queries = ch.count;
@@ -669,6 +678,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         fp.cost_ie = relative ? 2u * fp.cost_e : fp.cost_e;
         fp.cost_ioe = relative ? fp.cost_oe + fp.cost_e : fp.cost_oe;
         fp.pred_k = relative ? b->d_pred_k.p : nullptr;
+        fp.d_slot = b->d_dslot.p; fp.pred_dslot = b->d_pred_dslot.p;
         fp.pipeline_error = b->d_pipeline_error.p;
         const uint32_t blocks = (ch.count + 3) / 4;
 #define LAUNCH_FWD(QQ, TT)                                                                                              \

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
     const uint32_t pitch = P.pitch[qi];
     const uint64_t RP = (uint64_t)P.n_rows * pitch;
     uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
-    uint16_t* __restrict__ Ip = Mp + RP;  // holds the 4-bit codes
-    uint16_t* __restrict__ Dp = Ip + RP;
+    uint16_t* __restrict__ Ip = Mp + RP;  // holds the 4-bit codes (a quarter plane)
+    uint16_t* __restrict__ Dp = Ip + RP / 4;  // the kept D rows, row r at slot d_slot[r] (compact_plane_elems)
     uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;
     const uint32_t e = P.cost_e, oe = P.cost_oe, x = P.cost_x;
     const uint32_t e2 = e | (e << 16), oe2 = oe | (oe << 16), x2 = x | (x << 16);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                     if (act[m]) {
                         *reinterpret_cast<uint4*>(Mp + rbase + m * QW) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
                         if (keep_d)
-                            *reinterpret_cast<uint4*>(Dp + rbase + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
+                            *reinterpret_cast<uint4*>(Dp + (uint64_t)P.d_slot[r] * pitch + sbase + K * lane + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
                         codes[m * (QW / 8)] = word;
                     }
                 }
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                 // reads 2-4 predecessor rows on every row).
                 constexpr int PB = Q == 1 ? 4 : 2;
                 const CPredRows* cpred = (const CPredRows*)P.pred_rows + meta.pred_begin;
+                const CPredRows* cpslot = (const CPredRows*)P.pred_dslot + meta.pred_begin;
                 for (uint32_t pe0 = 0; pe0 < meta.pred_count; pe0 += PB) {
                     uint32_t prs[PB];
                     bool valid[PB], in_regs[PB];
@@ -327,12 +328,13 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
 #pragma unroll
                     for (int b = 0; b < PB; ++b) {
                         const uint64_t pbase = (uint64_t)prs[b] * pitch + sbase + K * lane;
+                        const uint64_t pbase_d = (uint64_t)(valid[b] ? cpslot[pe0 + b] : 0u) * pitch + sbase + K * lane;
 #pragma unroll
                         for (int m = 0; m < Q; ++m) {
                             la[b][m] = make_uint4(inf2, inf2, inf2, inf2); lb[b][m] = la[b][m];
                             if (valid[b] && !in_regs[b] && act[m]) {
                                 la[b][m] = *reinterpret_cast<const uint4*>(Mp + pbase + m * QW);
-                                lb[b][m] = *reinterpret_cast<const uint4*>(Dp + pbase + m * QW);
+                                lb[b][m] = *reinterpret_cast<const uint4*>(Dp + pbase_d + m * QW);
                             }
                         }
                         edges[b] = inf2;

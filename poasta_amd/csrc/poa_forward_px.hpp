@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     const uint32_t pitch = P.pitch[qi];  // <= 1024 (launcher: one strip)
     const uint64_t RP = (uint64_t)P.n_rows * pitch;
     uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
-    uint16_t* __restrict__ Ip = Mp + RP;  // holds the flag bit-planes
-    uint16_t* __restrict__ Dp = Ip + RP;
+    uint16_t* __restrict__ Ip = Mp + RP;  // holds the flag bit-planes (a quarter plane)
+    uint16_t* __restrict__ Dp = Ip + RP / 4;  // the kept D rows, row r at slot d_slot[r] (compact_plane_elems)
     // deletion and insertion costs apart (they differ under the relative encoding, FwdParams::cost_de ..); the end row's
     // deletion always costs the plain e
     const uint32_t e = P.cost_ie, x = P.cost_x;
@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     const CRowWords* crows = (const CRowWords*)P.rows;
     const CU32* cpred = (const CU32*)P.pred_rows;
     const CU32* cpredk = (const CU32*)P.pred_k;  // relative encoding: e * pred_k is added to what a predecessor hands over
+    const CU32* cslot = (const CU32*)P.d_slot;
+    const CU32* cpslot = (const CU32*)P.pred_dslot;
 
     // predecessor minima of the last multi-predecessor row: sibling rows (ROW_SAME_PREDS) reuse them
     uint32_t PMc[K], PDc[K], PMlc = INF2;
@@ -224,13 +226,14 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);  // [C.q0, D.q0, C.q1, D.q1]
             uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (MF ? (uint64_t)r * mf_code_stride(pitch) : (uint64_t)r * (pitch / 8)) + lane;
             const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+            const uint64_t dbase = keep_d ? (uint64_t)cslot[r] * pitch + K * lane : 0;
             if (act_lo) {
                 *reinterpret_cast<uint4*>(Mp + rbase) =
                     make_uint4(pk_lo_lo(Ms[0], Ms[1]), pk_lo_lo(Ms[2], Ms[3]), pk_lo_lo(Ms[4], Ms[5]), pk_lo_lo(Ms[6], Ms[7]));
                 if (MF) codes[0] = __builtin_amdgcn_perm(accD, accB, 0x06020400u);  // [B.q0, D.q0, B.q1, D.q1]
                 else codes[0] = pk_lo_lo(ab, cd);
                 if (keep_d)
-                    *reinterpret_cast<uint4*>(Dp + rbase) =
+                    *reinterpret_cast<uint4*>(Dp + dbase) =
                         make_uint4(pk_lo_lo(Dc[0], Dc[1]), pk_lo_lo(Dc[2], Dc[3]), pk_lo_lo(Dc[4], Dc[5]), pk_lo_lo(Dc[6], Dc[7]));
             }
             if (act_hi) {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     make_uint4(pk_hi_hi(Ms[0], Ms[1]), pk_hi_hi(Ms[2], Ms[3]), pk_hi_hi(Ms[4], Ms[5]), pk_hi_hi(Ms[6], Ms[7]));
                 if (!MF) codes[QW / 8] = pk_hi_hi(ab, cd);
                 if (keep_d)
-                    *reinterpret_cast<uint4*>(Dp + rbase + QW) =
+                    *reinterpret_cast<uint4*>(Dp + dbase + QW) =
                         make_uint4(pk_hi_hi(Dc[0], Dc[1]), pk_hi_hi(Dc[2], Dc[3]), pk_hi_hi(Dc[4], Dc[5]), pk_hi_hi(Dc[6], Dc[7]));
             }
         };
@@ -263,14 +266,15 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     for (int k = 0; k < K; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
                 } else {
                     const uint64_t pbase = (uint64_t)pr * pitch + K * lane;
+                    const uint64_t pbase_d = (uint64_t)cpslot[meta.pred_begin + pe] * pitch + K * lane;
                     uint4 m0 = make_uint4(INF2, INF2, INF2, INF2), d0 = m0, m1 = m0, d1 = m0;
                     if (act_lo) {
                         m0 = *reinterpret_cast<const uint4*>(Mp + pbase);
-                        d0 = *reinterpret_cast<const uint4*>(Dp + pbase);
+                        d0 = *reinterpret_cast<const uint4*>(Dp + pbase_d);
                     }
                     if (act_hi) {
                         m1 = *reinterpret_cast<const uint4*>(Mp + pbase + QW);
-                        d1 = *reinterpret_cast<const uint4*>(Dp + pbase + QW);
+                        d1 = *reinterpret_cast<const uint4*>(Dp + pbase_d + QW);
                     }
                     const uint32_t a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
                     const uint32_t b0[4] = {d0.x, d0.y, d0.z, d0.w}, b1[4] = {d1.x, d1.y, d1.z, d1.w};
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
     const uint64_t RP = (uint64_t)P.n_rows * pitch;
     uint16_t* __restrict__ Mp = reinterpret_cast<uint16_t*>(P.planes) + P.plane_off[qi];
     uint16_t* __restrict__ Ip = Mp + RP;
-    uint16_t* __restrict__ Dp = Ip + RP;
+    uint16_t* __restrict__ Dp = Ip + RP / 4;  // see poa_forward_px_kernel
     uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;
     const uint32_t e = P.cost_ie, x = P.cost_x;   // see poa_forward_px_kernel
     const uint32_t e2 = e | (e << 16), ioe2 = P.cost_ioe | (P.cost_ioe << 16), x2 = x | (x << 16);
@@ -362,6 +366,8 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
     const CRowWords* crows = (const CRowWords*)P.rows;
     const CU32* cpred = (const CU32*)P.pred_rows;
     const CU32* cpredk = (const CU32*)P.pred_k;  // relative encoding: e * pred_k is added to what a predecessor hands over
+    const CU32* cslot = (const CU32*)P.d_slot;
+    const CU32* cpslot = (const CU32*)P.pred_dslot;
 
     for (uint32_t g = 0; g < n_groups; ++g) {
         const uint32_t s = g * S + wave;
@@ -392,8 +398,12 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
 #pragma unroll
         for (int k = 0; k < K; ++k) { PMc[k] = INF2; PDc[k] = INF2; }
 
+        // the row record is read one row ahead: with two or three waves per SIMD (a chunk of long queries) nothing else hides
+        // the scalar load's latency at the head of every row
+        poa_u32x4 mw_ahead = crows[0];
         auto do_row = [&](const uint32_t r, const uint32_t (&Mprev)[K], const uint32_t (&Dprev)[K], uint32_t (&Mout)[K], uint32_t (&Dout)[K]) {
-            const poa_u32x4 mw = crows[r];
+            const poa_u32x4 mw = mw_ahead;
+            mw_ahead = crows[r + 1 < P.n_rows ? r + 1 : r];
             struct { uint32_t pred_begin, pred_count, sym, child_sym, flags; } meta{mw.y, mw.z, mw.w & 0xFFu, (mw.w >> 8) & 0xFFu, (mw.w >> 16) & 0xFFu};
             const uint32_t sym2 = meta.sym | (meta.sym << 16);
             const uint64_t rbase = (uint64_t)r * pitch + sbase + K * lane;
@@ -477,12 +487,13 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                 const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);
                 uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
                 const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
+                const uint64_t dbase = keep_d ? (uint64_t)cslot[r] * pitch + sbase + K * lane : 0;
                 if (act_lo) {
                     *reinterpret_cast<uint4*>(Mp + rbase) =
                         make_uint4(pk_lo_lo(Mc[0], Mc[1]), pk_lo_lo(Mc[2], Mc[3]), pk_lo_lo(Mc[4], Mc[5]), pk_lo_lo(Mc[6], Mc[7]));
                     codes[0] = pk_lo_lo(ab, cd);
                     if (keep_d)
-                        *reinterpret_cast<uint4*>(Dp + rbase) =
+                        *reinterpret_cast<uint4*>(Dp + dbase) =
                             make_uint4(pk_lo_lo(Dc[0], Dc[1]), pk_lo_lo(Dc[2], Dc[3]), pk_lo_lo(Dc[4], Dc[5]), pk_lo_lo(Dc[6], Dc[7]));
                 }
                 if (act_hi) {
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                         make_uint4(pk_hi_hi(Mc[0], Mc[1]), pk_hi_hi(Mc[2], Mc[3]), pk_hi_hi(Mc[4], Mc[5]), pk_hi_hi(Mc[6], Mc[7]));
                     codes[QW / 8] = pk_hi_hi(ab, cd);
                     if (keep_d)
-                        *reinterpret_cast<uint4*>(Dp + rbase + QW) =
+                        *reinterpret_cast<uint4*>(Dp + dbase + QW) =
                             make_uint4(pk_hi_hi(Dc[0], Dc[1]), pk_hi_hi(Dc[2], Dc[3]), pk_hi_hi(Dc[4], Dc[5]), pk_hi_hi(Dc[6], Dc[7]));
                 }
                 // what the next strip needs of this row: I and M of my last column (quad 1, lane 63, register 7)
@@ -523,14 +534,15 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                         for (int k = 0; k < K; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
                     } else {
                         const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
+                        const uint64_t pbase_d = (uint64_t)cpslot[meta.pred_begin + pe] * pitch + sbase + K * lane;
                         uint4 m0 = make_uint4(INF2, INF2, INF2, INF2), d0 = m0, m1 = m0, d1 = m0;
                         if (act_lo) {
                             m0 = *reinterpret_cast<const uint4*>(Mp + pbase);
-                            d0 = *reinterpret_cast<const uint4*>(Dp + pbase);
+                            d0 = *reinterpret_cast<const uint4*>(Dp + pbase_d);
                         }
                         if (act_hi) {
                             m1 = *reinterpret_cast<const uint4*>(Mp + pbase + QW);
-                            d1 = *reinterpret_cast<const uint4*>(Dp + pbase + QW);
+                            d1 = *reinterpret_cast<const uint4*>(Dp + pbase_d + QW);
                         }
                         const uint32_t a0[4] = {m0.x, m0.y, m0.z, m0.w}, a1[4] = {m1.x, m1.y, m1.z, m1.w};
                         const uint32_t b0[4] = {d0.x, d0.y, d0.z, d0.w}, b1[4] = {d1.x, d1.y, d1.z, d1.w};

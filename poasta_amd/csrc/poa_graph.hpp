@@ -47,6 +47,16 @@ inline uint32_t ex_cell_index32(uint32_t row, uint32_t off, uint32_t st, uint32_
     return 3u * rows_t * pitch + (st * (n_rows - rows_t) + (row - rows_t)) * pitch + off;
 }
 
+// Compact layout of one query, in 2-byte elements: [M: rows * pitch][4 flag bits per cell: rows * pitch / 4][kept D rows:
+// n_store_d * pitch] (pitch is a multiple of 64, so every part starts 16-byte aligned)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t compact_plane_elems(uint32_t rows, uint32_t pitch, uint32_t n_store_d) {
+    const uint64_t rp = (uint64_t)rows * pitch;
+    return rp + rp / 4 + (uint64_t)n_store_d * pitch;
+}
+
 struct RowMeta {  // 16 bytes, one per row
     uint32_t node;        // node index in the host graph (rpos of AlignedPair)
     uint32_t pred_begin;  // first entry in pred_rows
@@ -75,6 +85,10 @@ struct FlatGraph {
     // matched to a query symbol), under which every move keeps a non-negative cost: the deletion extension becomes
     // e * pred_k, the (mis)match x * [differs] + e * pred_k, the insertion extension 2e, where
     // pred_k[edge p -> r] = 1 + row_depth[p] - row_depth[r] >= 0 (0 along every shortest path, in particular for chain rows).
+    // Compact plane layout: only rows flagged ROW_STORE_D keep their D row; those rows are stored back to back, row r at
+    // slot d_slot[r] (0xFFFFFFFF: not kept); pred_dslot[k] = d_slot[pred_rows[k]] saves the dependent lookup.
+    std::vector<uint32_t> d_slot, pred_dslot;
+    uint32_t n_store_d = 0;
     std::vector<uint32_t> row_depth;     // [n]
     std::vector<uint32_t> pred_k;        // [pred_rows.size()]
 

@@ -55,6 +55,9 @@ struct FwdParams {
     // pred_k = nullptr.  The end row's deletion always costs cost_e.
     uint32_t cost_de, cost_doe, cost_ie, cost_ioe;
     const uint32_t* pred_k;     // [n_edges] or nullptr
+    // compact layout (FlatGraph::d_slot / pred_dslot): where the kept D rows live
+    const uint32_t* d_slot;     // [n_rows]
+    const uint32_t* pred_dslot; // [n_edges]
     uint32_t* pipeline_error;   // one word: set when a wave of the multi-wave pipeline gave up waiting (a protocol bug, not an input)
 };
 
@@ -83,6 +86,8 @@ struct TbParams {
     uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel<false>),
                                   // 2 = flags A, C in bits 14, 15 of the stored M value, B, D as bit-planes (poa_forward_px_kernel<true>)
     const uint32_t* row_depth;    // relative encoding: stored value = score - e * (row_depth[row] - column); nullptr: absolute
+    const uint32_t* d_slot;       // compact layout: slot of a row's kept D row (FlatGraph::d_slot / pred_dslot)
+    const uint32_t* pred_dslot;
 };
 
 __device__ __forceinline__ uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -169,6 +174,8 @@ struct TbCtx {
     uint32_t L, pitch, start_row, end_row;
     uint32_t x, o, e;
     const uint32_t* row_depth;  // relative encoding (TbParams::row_depth) or nullptr
+    const uint32_t* d_slot;     // compact layout: c.D holds only the kept D rows, row r at slot d_slot[r]
+    const uint32_t* pred_dslot;
 };
 
 struct TbStep {
@@ -224,6 +231,12 @@ __device__ __forceinline__ uint32_t plD(const TbCtx<T>& c, uint32_t row, uint32_
         return tb_abs(c, PlaneIO<T>::get(c.D + (uint64_t)row * c.pitch + j), depth, j);
     }
     return PlaneIO<T>::get(c.D + (uint64_t)row * c.pitch + j);
+}
+// compact layout: D of the kept row stored at `slot` (the row itself only enters the relative encoding)
+template <typename T>
+__device__ __forceinline__ uint32_t plDslot(const TbCtx<T>& c, uint32_t slot, uint32_t row, uint32_t j) {
+    const uint32_t v = PlaneIO<T>::get(c.D + (uint64_t)slot * c.pitch + j);
+    return c.row_depth ? tb_abs(c, v, c.row_depth[row], j) : v;
 }
 template <typename T>
 __device__ __forceinline__ uint32_t plI(const TbCtx<T>& c, uint32_t row, uint32_t j) {
@@ -325,11 +338,14 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
             if (tb_code(c, row, j) & 8u) cand(row - 1, j, 1);
         } else {
             for (uint32_t pe0 = 0; pe0 < m.pred_count; pe0 += 4) {
-                uint32_t prs[4], vals[4];
+                uint32_t prs[4], vals[4], slots[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) prs[b] = (pe0 + b < m.pred_count) ? c.pred_rows[m.pred_begin + pe0 + b] : 0u;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) vals[b] = (pe0 + b < m.pred_count) ? plD(c, prs[b], j) : INF;  // predecessors of a non-chain row keep their D row
+                for (int b = 0; b < 4; ++b) slots[b] = (COMPACT && pe0 + b < m.pred_count) ? c.pred_dslot[m.pred_begin + pe0 + b] : 0u;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)  // predecessors of a non-chain row keep their D row
+                    vals[b] = (pe0 + b < m.pred_count) ? (COMPACT ? plDslot(c, slots[b], prs[b], j) : plD(c, prs[b], j)) : INF;
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     if (pe0 + b < m.pred_count && vals[b] == t_ext) cand(prs[b], j, 1);
@@ -387,8 +403,9 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     const uint64_t RP = (uint64_t)P.n_rows * c.pitch;
     c.M = reinterpret_cast<const T*>(P.planes) + P.plane_off[qi];
     c.I = c.M + RP;
-    c.D = c.I + RP;
+    c.D = c.I + (COMPACT ? RP / 4 : RP);   // compact: the flag codes take a quarter plane, then the kept D rows (compact_plane_elems)
     c.codes = reinterpret_cast<const uint32_t*>(c.I);
+    c.d_slot = P.d_slot; c.pred_dslot = P.pred_dslot;
     c.code_fmt = P.code_fmt;
     c.tiled = P.exact_pass;  // the replayed search leaves its table tiled
     c.n_rows = P.n_rows;
@@ -435,7 +452,11 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
             if (!cur.found && !pn) {
                 // the end row has no insertion state (I[end] = INF) and keeps its D row in every layout
                 cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 2, INF, nc, bad, pn);  // (full planes: the stored I value is used)
-                if (!cur.found && !pn) { cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, plD(c, tb_row, tb_off), nc, bad, pn); fg = cur.cs; }
+                if (!cur.found && !pn) {
+                    const uint32_t d_end = COMPACT ? plDslot(c, c.d_slot[tb_row], tb_row, tb_off) : plD(c, tb_row, tb_off);
+                    cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, d_end, nc, bad, pn);
+                    fg = cur.cs;
+                }
                 // no backtrace from the end cell: the reference builds a 'simple alignment' for len <= 3 and panics otherwise
                 // (gap_affine.rs:838-853); on a replayed table that is exactly what happened, so only len > 3 is a panic
                 if (!pn) {
@@ -618,7 +639,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
     const uint64_t RP = (uint64_t)P.n_rows * pitch;
     T* __restrict__ Mp = reinterpret_cast<T*>(P.planes) + P.plane_off[qi];
     T* __restrict__ Ip = Mp + RP;
-    T* __restrict__ Dp = Ip + RP;
+    T* __restrict__ Dp = Ip + (COMPACT ? RP / 4 : RP);   // compact: codes, then the kept D rows at their slots
     uint32_t* __restrict__ carry = P.strip_carry + 2ull * wq * P.n_rows;  // [2r]: I entering the next strip, [2r+1]: I of my last column
     const uint32_t x = P.cost_x, oe = P.cost_oe, e = P.cost_e;
     const uint32_t n_strips = (pitch + W - 1) / W;
@@ -706,6 +727,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
                 for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
                     const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
                     const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
+                    const uint64_t pbase_d = COMPACT ? (uint64_t)P.pred_dslot[meta.pred_begin + pe] * pitch + sbase + K * lane : pbase;
                     uint32_t tm[C], td[C];
                     if (pr + 1 == r) {
 #pragma unroll
@@ -718,7 +740,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
                             for (int k = 0; k < K; ++k) { a[k] = INF; b[k] = INF; }
                             if (act[m]) {
                                 IO::load(Mp + pbase + m * QW, a);
-                                IO::load(Dp + pbase + m * QW, b);
+                                IO::load(Dp + pbase_d + m * QW, b);
                             }
 #pragma unroll
                             for (int k = 0; k < K; ++k) { tm[K * m + k] = a[k]; td[K * m + k] = b[k]; }
@@ -821,7 +843,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
                     }
                     if (act[m]) {
                         IO::store(Mp + rbase + m * QW, &Mc[K * m]);
-                        if (keep_d) IO::store(Dp + rbase + m * QW, &Dc[K * m]);
+                        if (keep_d) IO::store(Dp + (uint64_t)P.d_slot[r] * pitch + sbase + K * lane + m * QW, &Dc[K * m]);
                         codes[m * (QW / 8)] = code;
                     }
                 }

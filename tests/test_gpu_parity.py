@@ -244,9 +244,10 @@ def test_u16_planes_by_score_upper_bound(engine, oracle):
     _check_against_astar(oracle, poa.graph, qs, res, costs=(255, 2, 1), heuristic=oracle.H_DIJKSTRA, pruning=False)
 
 
-def test_chunked_workspace_uses_both_plans(engine, oracle):
-    """A workspace too small for the batch: the u16 layouts pack twice the queries per chunk (plan 1), the exact
-    replay runs on the u32 plan (plan 0); results equal the unchunked run's either way."""
+def test_chunked_workspace_uses_every_plan(engine, oracle):
+    """A workspace too small for the batch: the compact layout is packed at its real size (M + flag codes + the kept D rows,
+    plan 2), three full u16 planes take half the u32 space (plan 1), the exact replay runs on the u32 plan (plan 0); results
+    equal the unchunked run's every way."""
     g, (qseq, qoff) = W.scaled_linearish(200, 10, 5, 24, 180)
     costs = _costs(engine)
     whole = engine.ResidentBatch(g, qseq, qoff)
@@ -258,12 +259,14 @@ def test_chunked_workspace_uses_both_plans(engine, oracle):
     a = rb.fetch()
     import os
     if os.environ.get("POA_PLANES") != "32":              # (the debug override forces the u32 plan)
-        assert a.stats["n_chunks"] == 3                  # 10 queries per chunk in 2-byte elements
+        assert a.stats["n_chunks"] == 2                  # compact layout: < 3 of the 12 bytes per cell of the u32 planes
     rb.run(costs, None, engine.make_config("exact"))
     e = rb.fetch()
     assert e.stats["n_chunks"] == 5                      # 5 per chunk in 4-byte elements
     rb.run(costs, None, engine.make_config(full_planes=True))
     f = rb.fetch()
+    if os.environ.get("POA_PLANES") != "32":
+        assert f.stats["n_chunks"] == 3                  # 10 queries per chunk in 2-byte elements, three planes
     assert np.array_equal(a.score, ref.score) and np.array_equal(f.score, ref.score) and np.array_equal(e.score, ref.score)
     assert np.array_equal(a.flags, ref.flags) and np.array_equal(f.flags, ref.flags)
     og = oracle.OracleGraph.from_csr(g.as_dict())

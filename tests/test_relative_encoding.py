@@ -129,14 +129,16 @@ def test_relative_with_other_costs_and_the_msa_graph(engine):
 
 
 def test_relative_hybrid_is_the_reference(engine, oracle):
-    """Hybrid mode on top of a relative dense pass: the replay takes its order and its flags from that pass."""
-    g, sym = _long_bubbly_graph(5, 38000, n_bypass=4, n_branch=20, n_snp=200, two_ends=False)
-    qs = _window_queries(55, sym, 6, 200, 700)[:6]
+    """Hybrid mode on top of a relative dense pass: the replay takes its order and its flags from that pass.  (A steep
+    gap-extend cost puts a 1 500-node graph beyond u16, which keeps the replayed searches short.)"""
+    g, sym = _long_bubbly_graph(5, 1500, n_bypass=3, n_branch=6, n_snp=40, two_ends=False)
+    qs = _window_queries(55, sym, 6, 80, 200)[:6]
     qseq, qoff = pack_queries(qs)
-    res, layout = _run(engine, g, qseq, qoff, {}, config=engine.make_config("hybrid"))
-    assert "relative" in layout
+    costs = (4, 6, 60)
+    res, layout = _run(engine, g, qseq, qoff, {}, costs, config=engine.make_config("hybrid"))
+    assert "relative" in layout and int(res.score.min()) > 65534
     og = oracle.OracleGraph.from_csr(g.as_dict())
-    A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=6)
+    A = og.astar_batch(qseq, qoff, oracle.Costs(*costs), oracle.H_MINGAP, True, threads=6)
     for i in range(len(qs)):
         assert A["status"][i] == 0
         assert int(res.score[i]) == int(A["score"][i])
