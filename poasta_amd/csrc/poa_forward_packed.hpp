@@ -257,7 +257,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
                     if (act[m]) {
                         *reinterpret_cast<uint4*>(Mp + rbase + m * QW) = make_uint4(Mc[4 * m], Mc[4 * m + 1], Mc[4 * m + 2], Mc[4 * m + 3]);
                         if (keep_d)
-                            *reinterpret_cast<uint4*>(Dp + (uint64_t)P.d_slot[r] * pitch + sbase + K * lane + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
+                            *reinterpret_cast<uint4*>(Dp + (uint64_t)(P.d_slot ? P.d_slot[r] : r) * pitch + sbase + K * lane + m * QW) = make_uint4(Dc[4 * m], Dc[4 * m + 1], Dc[4 * m + 2], Dc[4 * m + 3]);
                         codes[m * (QW / 8)] = word;
                     }
                 }
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(MW ? 1024 : 256) void poa_forward_packed_kernel(Fwd
 #pragma unroll
                     for (int b = 0; b < PB; ++b) {
                         const uint64_t pbase = (uint64_t)prs[b] * pitch + sbase + K * lane;
-                        const uint64_t pbase_d = (uint64_t)(valid[b] ? cpslot[pe0 + b] : 0u) * pitch + sbase + K * lane;
+                        const uint64_t pbase_d = P.pred_dslot ? (uint64_t)(valid[b] ? cpslot[pe0 + b] : 0u) * pitch + sbase + K * lane : pbase;
 #pragma unroll
                         for (int m = 0; m < Q; ++m) {
                             la[b][m] = make_uint4(inf2, inf2, inf2, inf2); lb[b][m] = la[b][m];

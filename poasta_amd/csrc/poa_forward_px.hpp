@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);  // [C.q0, D.q0, C.q1, D.q1]
             uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (MF ? (uint64_t)r * mf_code_stride(pitch) : (uint64_t)r * (pitch / 8)) + lane;
             const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
-            const uint64_t dbase = keep_d ? (uint64_t)cslot[r] * pitch + K * lane : 0;
+            const uint64_t dbase = keep_d ? (uint64_t)(cslot ? cslot[r] : r) * pitch + K * lane : 0;
             if (act_lo) {
                 *reinterpret_cast<uint4*>(Mp + rbase) =
                     make_uint4(pk_lo_lo(Ms[0], Ms[1]), pk_lo_lo(Ms[2], Ms[3]), pk_lo_lo(Ms[4], Ms[5]), pk_lo_lo(Ms[6], Ms[7]));
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     for (int k = 0; k < K; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
                 } else {
                     const uint64_t pbase = (uint64_t)pr * pitch + K * lane;
-                    const uint64_t pbase_d = (uint64_t)cpslot[meta.pred_begin + pe] * pitch + K * lane;
+                    const uint64_t pbase_d = cpslot ? (uint64_t)cpslot[meta.pred_begin + pe] * pitch + K * lane : pbase;
                     uint4 m0 = make_uint4(INF2, INF2, INF2, INF2), d0 = m0, m1 = m0, d1 = m0;
                     if (act_lo) {
                         m0 = *reinterpret_cast<const uint4*>(Mp + pbase);
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                 const uint32_t cd = __builtin_amdgcn_perm(accD, accC, 0x06020400u);
                 uint32_t* __restrict__ codes = reinterpret_cast<uint32_t*>(Ip) + (uint64_t)r * (pitch / 8) + sbase / 8 + lane;
                 const bool keep_d = (meta.flags & ROW_STORE_D) != 0;
-                const uint64_t dbase = keep_d ? (uint64_t)cslot[r] * pitch + sbase + K * lane : 0;
+                const uint64_t dbase = keep_d ? (uint64_t)(cslot ? cslot[r] : r) * pitch + sbase + K * lane : 0;
                 if (act_lo) {
                     *reinterpret_cast<uint4*>(Mp + rbase) =
                         make_uint4(pk_lo_lo(Mc[0], Mc[1]), pk_lo_lo(Mc[2], Mc[3]), pk_lo_lo(Mc[4], Mc[5]), pk_lo_lo(Mc[6], Mc[7]));
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                         for (int k = 0; k < K; ++k) { tm[k] = Mprev[k]; td[k] = Dprev[k]; }
                     } else {
                         const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
-                        const uint64_t pbase_d = (uint64_t)cpslot[meta.pred_begin + pe] * pitch + sbase + K * lane;
+                        const uint64_t pbase_d = cpslot ? (uint64_t)cpslot[meta.pred_begin + pe] * pitch + sbase + K * lane : pbase;
                         uint4 m0 = make_uint4(INF2, INF2, INF2, INF2), d0 = m0, m1 = m0, d1 = m0;
                         if (act_lo) {
                             m0 = *reinterpret_cast<const uint4*>(Mp + pbase);

@@ -158,12 +158,22 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
         for (uint32_t pe = 0; pe < m.pred_count; ++pe) g.rows[g.pred_rows[m.pred_begin + pe]].flags |= ROW_STORE_D;
     }
     // compact layout: the kept D rows are stored densely, row r at slot d_slot[r]
-    g.d_slot.assign(n, 0xFFFFFFFFu);
-    g.n_store_d = 0;
-    for (uint32_t r = 0; r < n; ++r)
-        if (g.rows[r].flags & ROW_STORE_D) g.d_slot[r] = g.n_store_d++;
-    g.pred_dslot.assign(g.pred_rows.size(), 0xFFFFFFFFu);
-    for (size_t k = 0; k < g.pred_rows.size(); ++k) g.pred_dslot[k] = g.d_slot[g.pred_rows[k]];
+    // (a graph that keeps most of its D rows anyway — bubble-rich: every row has several predecessors — stores them by row:
+    // d_slot stays empty, the kernels skip the lookup)
+    {
+        uint32_t kept = 0;
+        for (uint32_t r = 0; r < n; ++r) kept += (g.rows[r].flags & ROW_STORE_D) ? 1u : 0u;
+        g.d_slot.clear(); g.pred_dslot.clear();
+        g.n_store_d = n;
+        if (2ull * kept <= n) {
+            g.d_slot.assign(n, 0xFFFFFFFFu);
+            g.n_store_d = 0;
+            for (uint32_t r = 0; r < n; ++r)
+                if (g.rows[r].flags & ROW_STORE_D) g.d_slot[r] = g.n_store_d++;
+            g.pred_dslot.assign(g.pred_rows.size(), 0xFFFFFFFFu);
+            for (size_t k = 0; k < g.pred_rows.size(); ++k) g.pred_dslot[k] = g.d_slot[g.pred_rows[k]];
+        }
+    }
     // shortest start -> end path, in real nodes (bounds the optimal score from above: see poa_batch_run_ex)
     {
         std::vector<uint32_t> dist(n, 0xFFFFFFFFu);

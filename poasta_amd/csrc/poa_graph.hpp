@@ -86,7 +86,8 @@ struct FlatGraph {
     // e * pred_k, the (mis)match x * [differs] + e * pred_k, the insertion extension 2e, where
     // pred_k[edge p -> r] = 1 + row_depth[p] - row_depth[r] >= 0 (0 along every shortest path, in particular for chain rows).
     // Compact plane layout: only rows flagged ROW_STORE_D keep their D row; those rows are stored back to back, row r at
-    // slot d_slot[r] (0xFFFFFFFF: not kept); pred_dslot[k] = d_slot[pred_rows[k]] saves the dependent lookup.
+    // slot d_slot[r] (0xFFFFFFFF: not kept); pred_dslot[k] = d_slot[pred_rows[k]] saves the dependent lookup.  Both empty
+    // (and n_store_d = n): the D rows are stored by row, for graphs that keep more than half of them.
     std::vector<uint32_t> d_slot, pred_dslot;
     uint32_t n_store_d = 0;
     std::vector<uint32_t> row_depth;     // [n]

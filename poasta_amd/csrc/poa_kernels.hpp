@@ -55,7 +55,7 @@ struct FwdParams {
     // pred_k = nullptr.  The end row's deletion always costs cost_e.
     uint32_t cost_de, cost_doe, cost_ie, cost_ioe;
     const uint32_t* pred_k;     // [n_edges] or nullptr
-    // compact layout (FlatGraph::d_slot / pred_dslot): where the kept D rows live
+    // compact layout (FlatGraph::d_slot / pred_dslot): where the kept D rows live; nullptr: stored by row
     const uint32_t* d_slot;     // [n_rows]
     const uint32_t* pred_dslot; // [n_edges]
     uint32_t* pipeline_error;   // one word: set when a wave of the multi-wave pipeline gave up waiting (a protocol bug, not an input)
@@ -342,7 +342,7 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
 #pragma unroll
                 for (int b = 0; b < 4; ++b) prs[b] = (pe0 + b < m.pred_count) ? c.pred_rows[m.pred_begin + pe0 + b] : 0u;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) slots[b] = (COMPACT && pe0 + b < m.pred_count) ? c.pred_dslot[m.pred_begin + pe0 + b] : 0u;
+                for (int b = 0; b < 4; ++b) slots[b] = (COMPACT && c.pred_dslot && pe0 + b < m.pred_count) ? c.pred_dslot[m.pred_begin + pe0 + b] : prs[b];
 #pragma unroll
                 for (int b = 0; b < 4; ++b)  // predecessors of a non-chain row keep their D row
                     vals[b] = (pe0 + b < m.pred_count) ? (COMPACT ? plDslot(c, slots[b], prs[b], j) : plD(c, prs[b], j)) : INF;
@@ -453,7 +453,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
                 // the end row has no insertion state (I[end] = INF) and keeps its D row in every layout
                 cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 2, INF, nc, bad, pn);  // (full planes: the stored I value is used)
                 if (!cur.found && !pn) {
-                    const uint32_t d_end = COMPACT ? plDslot(c, c.d_slot[tb_row], tb_row, tb_off) : plD(c, tb_row, tb_off);
+                    const uint32_t d_end = COMPACT ? plDslot(c, c.d_slot ? c.d_slot[tb_row] : tb_row, tb_row, tb_off) : plD(c, tb_row, tb_off);
                     cur = tb_step<T, COMPACT>(c, tb_row, tb_off, 1, d_end, nc, bad, pn);
                     fg = cur.cs;
                 }
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
                 for (uint32_t pe = 0; pe < meta.pred_count; ++pe) {
                     const uint32_t pr = P.pred_rows[meta.pred_begin + pe];
                     const uint64_t pbase = (uint64_t)pr * pitch + sbase + K * lane;
-                    const uint64_t pbase_d = COMPACT ? (uint64_t)P.pred_dslot[meta.pred_begin + pe] * pitch + sbase + K * lane : pbase;
+                    const uint64_t pbase_d = (COMPACT && P.pred_dslot) ? (uint64_t)P.pred_dslot[meta.pred_begin + pe] * pitch + sbase + K * lane : pbase;
                     uint32_t tm[C], td[C];
                     if (pr + 1 == r) {
 #pragma unroll
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(MW ? (Q >= 4 ? 640 : 1024) : 256, POA_FWD_MIN_WAVES
                     }
                     if (act[m]) {
                         IO::store(Mp + rbase + m * QW, &Mc[K * m]);
-                        if (keep_d) IO::store(Dp + (uint64_t)P.d_slot[r] * pitch + sbase + K * lane + m * QW, &Dc[K * m]);
+                        if (keep_d) IO::store(Dp + (uint64_t)(P.d_slot ? P.d_slot[r] : r) * pitch + sbase + K * lane + m * QW, &Dc[K * m]);
                         codes[m * (QW / 8)] = code;
                     }
                 }

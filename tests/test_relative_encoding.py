@@ -131,7 +131,7 @@ def test_relative_with_other_costs_and_the_msa_graph(engine):
 def test_relative_hybrid_is_the_reference(engine, oracle):
     """Hybrid mode on top of a relative dense pass: the replay takes its order and its flags from that pass.  (A steep
     gap-extend cost puts a 1 500-node graph beyond u16, which keeps the replayed searches short.)"""
-    g, sym = _long_bubbly_graph(5, 1500, n_bypass=3, n_branch=6, n_snp=40, two_ends=False)
+    g, sym = _long_bubbly_graph(5, 1500, n_bypass=0, n_branch=6, n_snp=40, two_ends=False)
     qs = _window_queries(55, sym, 6, 80, 200)[:6]
     qseq, qoff = pack_queries(qs)
     costs = (4, 6, 60)
