@@ -240,7 +240,7 @@ def main():
         elif os.environ.get("POA_COMPACT") == "0" or os.environ.get("POA_PACKED") == "0":
             kernel_name = "poa_forward_kernel<2, unsigned short>"
         else:
-            kernel_name = "poa_forward_px_kernel<true>" if os.environ.get("POA_PX") != "0" else "poa_forward_packed_kernel<2>"
+            kernel_name = "poa_forward_px_kernel<2>" if os.environ.get("POA_PX") != "0" else "poa_forward_packed_kernel<2>"
         roof = {"kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3), "launches_timed": launches,
                 "cells_per_launch": int(cells_per_launch),
                 "alg_bytes_per_cell": ALG_BYTES_PER_CELL, "alg_achieved_GBps": round(alg_achieved, 1),

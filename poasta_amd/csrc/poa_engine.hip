@@ -722,11 +722,13 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 if (const char* xv = getenv("POA_PX")) px = (px && atoi(xv) != 0) || (px && relative);
                 if (px) {
                     // scores below 0x3FFF (same bound as for u16, one power lower): two flags ride in the stored M value
-                    bool mf = ub <= 16382 && !relative;
-                    if (const char* fv2 = getenv("POA_MF")) mf = mf && atoi(fv2) != 0;
-                    tp.code_fmt = mf ? 2u : 1u;
-                    if (mf) hipLaunchKernelGGL(poa_forward_px_kernel<true>, dim3(blocks), dim3(256), 0, stream, fp);
-                    else hipLaunchKernelGGL(poa_forward_px_kernel<false>, dim3(blocks), dim3(256), 0, stream, fp);
+                    // (below 0x0FFF: all four; POA_MF = 0 / 1 / 2 caps the variant for A-B runs)
+                    int mf = relative ? 0 : (ub <= 4094 ? 2 : (ub <= 16382 ? 1 : 0));
+                    if (const char* fv2 = getenv("POA_MF")) mf = std::min(mf, std::max(0, atoi(fv2)));
+                    tp.code_fmt = mf == 2 ? 3u : (mf == 1 ? 2u : 1u);
+                    if (mf == 2) hipLaunchKernelGGL(poa_forward_px_kernel<2>, dim3(blocks), dim3(256), 0, stream, fp);
+                    else if (mf == 1) hipLaunchKernelGGL(poa_forward_px_kernel<1>, dim3(blocks), dim3(256), 0, stream, fp);
+                    else hipLaunchKernelGGL(poa_forward_px_kernel<0>, dim3(blocks), dim3(256), 0, stream, fp);
                 } else if (mw && (relative || pxmw_ok(ch.count, max_pitch))) {
                     // pairs-across-quads mapping, 1024-column strips pipelined over the waves of a workgroup
                     tp.code_fmt = 1;

@@ -43,11 +43,14 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus_pk(uint32_t t, uint32_t s
 __device__ __forceinline__ uint32_t pk_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 __device__ __forceinline__ uint32_t pk_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-// MF (needs every relevant score < 0x3FFF, decided by the launcher from the bound on the optimal score): the two flags a
+// MF = 2 (every relevant score < 0x0FFF): all four flags ride in the stored M value — bits 12..15 = I[j]==I[j-1]+e, D==PD+e,
+// I==M, D==M over a 12-bit score (0x0FFF = INF) — and no flag words are written at all (TbParams::code_fmt 3): a tenth less
+// HBM traffic for a kernel whose stores cost a third of its time.
+// MF = 1 (needs every relevant score < 0x3FFF, decided by the launcher from the bound on the optimal score): the two flags a
 // Match-state traceback step reads — I == M, D == M — are stored in bits 14 and 15 of the M value itself (0x3FFF = INF,
 // larger finite values of irrelevant cells are clamped to it), and the flag plane keeps only the two gap-state flags
 // (one dword per lane and row).  The traceback then needs ONE load per diagonal step instead of two.
-template <bool MF>
+template <int MF>
 __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     constexpr int K = 8;                 // columns per lane and quad == packed registers per row array
     constexpr uint32_t QW = 64 * K;      // 512 columns per quad
@@ -121,8 +124,11 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 
     // one row: reads the previous row from (Mprev, Dprev), leaves this row in (Mout, Dout) — the caller alternates two
     // register sets so that no row ends with 16 register copies
+    // the row record is read one row ahead (four scalar registers): its s_load is not waited for at the head of the row
+    poa_u32x4 mw_ahead = crows[0];
     auto do_row = [&](const uint32_t r, const uint32_t (&Mprev)[K], const uint32_t (&Dprev)[K], uint32_t (&Mout)[K], uint32_t (&Dout)[K]) {
-        const poa_u32x4 mw = crows[r];  // {node, pred_begin, pred_count, sym | child_sym << 8 | flags << 16 | sym_idx << 24}
+        const poa_u32x4 mw = mw_ahead;  // {node, pred_begin, pred_count, sym | child_sym << 8 | flags << 16 | sym_idx << 24}
+        mw_ahead = crows[r + 1 < P.n_rows ? r + 1 : r];
         struct { uint32_t pred_begin, pred_count, sym, child_sym, flags, sym_idx; } meta{mw.y, mw.z, mw.w & 0xFFu, (mw.w >> 8) & 0xFFu, (mw.w >> 16) & 0xFFu, mw.w >> 24};
         const uint32_t sym = meta.sym;
         const uint32_t sym2 = sym | (sym << 16);
@@ -211,15 +217,20 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t fA = pk_eq_ge(Ic[k], Mc[k]), fC = pk_eq_ge(Dc[k], Mc[k]);
-                if (MF) {
+                const uint32_t fB = pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]), fD = pk_eq_ge(PDe[k], Dc[k]);
+                if (MF == 2) {
+                    Ms[k] = (fC << 15) | ((fA << 14) | ((fD << 13) | ((fB << 12) | pk_min(Mc[k], 0x0FFF0FFFu))));
+                } else if (MF == 1) {
                     Ms[k] = (fC << 15) | ((fA << 14) | pk_min(Mc[k], 0x3FFF3FFFu));
+                    accB |= fB << k;
+                    accD |= fD << k;
                 } else {
                     Ms[k] = Mc[k];
                     accA |= fA << k;
                     accC |= fC << k;
+                    accB |= fB << k;
+                    accD |= fD << k;
                 }
-                accB |= pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]) << k;
-                accD |= pk_eq_ge(PDe[k], Dc[k]) << k;
                 i_left = Ic[k];
             }
             const uint32_t ab = __builtin_amdgcn_perm(accB, accA, 0x06020400u);  // [A.q0, B.q0, A.q1, B.q1]
@@ -230,8 +241,8 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             if (act_lo) {
                 *reinterpret_cast<uint4*>(Mp + rbase) =
                     make_uint4(pk_lo_lo(Ms[0], Ms[1]), pk_lo_lo(Ms[2], Ms[3]), pk_lo_lo(Ms[4], Ms[5]), pk_lo_lo(Ms[6], Ms[7]));
-                if (MF) codes[0] = __builtin_amdgcn_perm(accD, accB, 0x06020400u);  // [B.q0, D.q0, B.q1, D.q1]
-                else codes[0] = pk_lo_lo(ab, cd);
+                if (MF == 1) codes[0] = __builtin_amdgcn_perm(accD, accB, 0x06020400u);  // [B.q0, D.q0, B.q1, D.q1]
+                else if (MF == 0) codes[0] = pk_lo_lo(ab, cd);
                 if (keep_d)
                     *reinterpret_cast<uint4*>(Dp + dbase) =
                         make_uint4(pk_lo_lo(Dc[0], Dc[1]), pk_lo_lo(Dc[2], Dc[3]), pk_lo_lo(Dc[4], Dc[5]), pk_lo_lo(Dc[6], Dc[7]));
@@ -284,12 +295,13 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                         td[2 * i] = pk_lo_lo(b0[i], b1[i]); td[2 * i + 1] = pk_hi_hi(b0[i], b1[i]);
                     }
                     if (MF) {
-                        // strip the flags; the 14-bit INF becomes the 16-bit one again
+                        // strip the flags; the 14-bit (12-bit) INF becomes the 16-bit one again
+                        constexpr uint32_t VM = MF == 2 ? 0x0FFF0FFFu : 0x3FFF3FFFu;
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            const uint32_t v = tm[k] & 0x3FFF3FFFu;
-                            const uint32_t is_inf = pku(pkv(0u) - pkv(pk_is_zero(v ^ 0x3FFF3FFFu)));  // 0xFFFF per half
-                            tm[k] = v | (is_inf & 0xC000C000u);
+                            const uint32_t v = tm[k] & VM;
+                            const uint32_t is_inf = pku(pkv(0u) - pkv(pk_is_zero(v ^ VM)));  // 0xFFFF per half
+                            tm[k] = v | (is_inf & ~VM);
                         }
                     }
                 }

@@ -84,7 +84,8 @@ struct TbParams {
     const uint32_t* ex_status;    // [total] 0 ok, 1 reference panic, 2 workspace overflow, 0xFFFFFFFF not replayed
     const uint32_t* ex_end;       // [2 * total] (row, offset) of the end cell the replayed search stopped at
     uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel<false>),
-                                  // 2 = flags A, C in bits 14, 15 of the stored M value, B, D as bit-planes (poa_forward_px_kernel<true>)
+                                  // 2 = flags A, C in bits 14, 15 of the stored M value, B, D as bit-planes (poa_forward_px_kernel<1>)
+                                  // 3 = flags B, D, A, C in bits 12..15 of the stored M value, no flag words (poa_forward_px_kernel<2>)
     const uint32_t* row_depth;    // relative encoding: stored value = score - e * (row_depth[row] - column); nullptr: absolute
     const uint32_t* d_slot;       // compact layout: slot of a row's kept D row (FlatGraph::d_slot / pred_dslot)
     const uint32_t* pred_dslot;
@@ -200,6 +201,9 @@ __device__ inline bool tb_open_i(const TbCtx<T>& c, const RowMeta& m, uint32_t j
 
 // code_fmt 2: a stored M value carries two flags — bit 14: I == M, bit 15: D == M — over a 14-bit score (0x3FFF = INF)
 constexpr uint32_t MF_MASK = 0x3FFFu;
+// code_fmt 3: four flags — bit 12: I[j] == I[j-1] + e, bit 13: D == PD + e, bit 14: I == M, bit 15: D == M — over a 12-bit score
+constexpr uint32_t MF4_MASK = 0x0FFFu;
+__device__ __forceinline__ uint32_t mf4_value(uint32_t raw) { const uint32_t v = raw & MF4_MASK; return v == MF4_MASK ? INF : v; }
 // dwords of [B, D] flag bit-planes per row: one per lane that owns columns of the row (a short row has fewer than 64)
 __host__ __device__ __forceinline__ uint32_t mf_code_stride(uint32_t pitch) { return pitch / 8 < 64u ? pitch / 8 : 64u; }
 __device__ __forceinline__ uint32_t mf_value(uint32_t raw) { const uint32_t v = raw & MF_MASK; return v == MF_MASK ? INF : v; }
@@ -217,6 +221,7 @@ template <typename T>
 __device__ __forceinline__ uint32_t plM(const TbCtx<T>& c, uint32_t row, uint32_t j) {
     if (c.tiled) return pl_tiled(c, row, j, 0);
     if (c.code_fmt == 2) return mf_value((uint32_t)c.M[(uint64_t)row * c.pitch + j]);
+    if (c.code_fmt == 3) return mf4_value((uint32_t)c.M[(uint64_t)row * c.pitch + j]);
     if (c.row_depth) {
         const uint32_t depth = c.row_depth[row];  // independent of the plane load: one round trip for both
         return tb_abs(c, PlaneIO<T>::get(c.M + (uint64_t)row * c.pitch + j), depth, j);
@@ -245,6 +250,10 @@ __device__ __forceinline__ uint32_t plI(const TbCtx<T>& c, uint32_t row, uint32_
 
 template <typename T>
 __device__ __forceinline__ uint32_t tb_code(const TbCtx<T>& c, uint32_t row, uint32_t j) {
+    if (c.code_fmt == 3) {  // all four flags in the cell's M value
+        const uint32_t raw = (uint32_t)c.M[(uint64_t)row * c.pitch + j];
+        return ((raw >> 14) & 1u) | (((raw >> 12) & 1u) << 1) | (((raw >> 15) & 1u) << 2) | (((raw >> 13) & 1u) << 3);
+    }
     if (c.code_fmt == 2) {  // one dword per lane and row: bytes [B quad 0, D quad 0, B quad 1, D quad 1], bit k = column 8l + k
         const uint32_t w = c.codes[(uint64_t)row * mf_code_stride(c.pitch) + ((j & 511u) >> 3)];
         const uint32_t sh = (j >> 9) * 16u + (j & 7u);
@@ -277,10 +286,10 @@ __device__ inline TbStep tb_step(const TbCtx<T>& c, uint32_t row, uint32_t j, ui
     if (st == 0) {
         // all loads of the step are issued before the first use (one memory round-trip for chain rows)
         uint32_t cs, dv = 0, iv = 0, code = 0;
-        if (COMPACT && c.code_fmt == 2) {
+        if (COMPACT && c.code_fmt >= 2) {
             // the two flags a Match-state step needs travel with the score: no code load on the common path
             const uint32_t raw = (uint32_t)c.M[(uint64_t)row * c.pitch + j];
-            cs = mf_value(raw);
+            cs = c.code_fmt == 3 ? mf4_value(raw) : mf_value(raw);
             code = ((raw >> 14) & 1u) | (((raw >> 15) & 1u) << 2);
         } else {
             cs = plM(c, row, j);

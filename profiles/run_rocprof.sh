@@ -24,10 +24,10 @@ for f in glob.glob("$OUT/pmc_*/*/*counter_collection.csv"):
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1, sort_keys=True)
 for f in glob.glob("$OUT/trace/*/*kernel_stats.csv"):
     open("$OUT/kernel_stats.csv", "w").write(open(f).read())
-k = next((v for n, v in out.items() if "poa_forward_px_kernel" in n), None)
+kname, k = next(((n, v) for n, v in out.items() if "poa_forward_px_kernel" in n), (None, None))
 if k and "WRITE_SIZE" in k and "FETCH_SIZE" in k:
     w, fch = k["WRITE_SIZE"] * 1024.0, k["FETCH_SIZE"] * 1024.0 * 2.0   # KiB -> bytes; gfx950 tallies 128-B fetches at 64 B
-    kc = {"workload": "config2", "queries": 10000, "kernel": "poa_amd::poa_forward_px_kernel<true>",
+    kc = {"workload": "config2", "queries": 10000, "kernel": kname.split("(")[0].replace("void ", ""),
           "hbm_bytes_per_launch": int(w + fch), "write_bytes": int(w), "fetch_bytes_corrected": int(fch),
           "sq_insts_valu_per_launch": k.get("SQ_INSTS_VALU"), "sq_insts_salu_per_launch": k.get("SQ_INSTS_SALU"),
           "sq_wave_cycles": k.get("SQ_WAVE_CYCLES"), "sq_wait_inst_any": k.get("SQ_WAIT_INST_ANY"), "sq_waves": k.get("SQ_WAVES"),

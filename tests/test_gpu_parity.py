@@ -314,3 +314,29 @@ def test_randomised_differential_run(engine):
     for args in (["--first", "81", "--seeds", "1"], ["--first", "409", "--seeds", "1"], ["--first", "2000", "--seeds", "48", "--seconds", "60"]):
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py")] + args, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_flag_encodings_of_the_one_strip_kernel_agree(engine, oracle):
+    """poa_forward_px_kernel stores the four traceback flags as bit-planes (code_fmt 1), two of them (code_fmt 2) or all four
+    (code_fmt 3) beside the score, as the bound on the optimal score allows; POA_MF caps the variant.  Same results each way."""
+    import os
+    g, (qseq, qoff) = W.scaled_linearish(600, 30, 15, 40, 700)
+    costs = _costs(engine)
+    runs = []
+    for cap in ("0", "1", "2"):
+        os.environ["POA_MF"] = cap
+        try:
+            rb = engine.ResidentBatch(g, qseq, qoff)
+            rb.run(costs)
+            runs.append(rb.fetch())
+            rb.close()
+        finally:
+            del os.environ["POA_MF"]
+    for r in runs[1:]:
+        assert np.array_equal(r.score, runs[0].score) and np.array_equal(r.flags, runs[0].flags)
+        assert np.array_equal(r.pair_off, runs[0].pair_off) and np.array_equal(r.pairs, runs[0].pairs)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    D = og.dense_batch(qseq, qoff, oracle.Costs(4, 6, 2), threads=4)
+    assert np.array_equal(runs[2].score, D["score"]) and np.array_equal(runs[2].flags, D["flags"])
+    for i in range(40):
+        assert runs[2].raw_alignment(i) == oracle.batch_alignment(D, i)
