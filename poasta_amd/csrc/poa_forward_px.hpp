@@ -39,6 +39,23 @@ __device__ __forceinline__ uint32_t wave_scan_min_plus_pk(uint32_t t, uint32_t s
     return P;
 }
 
+// The same scan on complemented values (c = 0xFFFF - v per half): min becomes max, the saturating add a saturating subtract,
+// and INF becomes 0 — which is what a DPP move hands a lane without a source under bound_ctrl, so no register has to be
+// preset to INF before every step (a v_mov and two wait states each).  All rows take part in the two broadcast steps
+// (row_mask 0xF): a row that the classic scan masks out receives a total it already holds or gets again later, harmless
+// under an idempotent max; the *_2 weights are the same per-lane constants (0 where a lane must not receive keeps it out:
+// callers pass 0xFFFF there, see w31c_2).
+__device__ __forceinline__ uint32_t wave_scan_max_minus_pk(uint32_t c, uint32_t step2, uint32_t w15_2, uint32_t w31c_2) {
+    uint32_t P = c;
+    P = pk_max(P, pk_sub_sat((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x111, 0xF, 0xF, true), step2));
+    P = pk_max(P, pk_sub_sat((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x112, 0xF, 0xF, true), 2 * step2));
+    P = pk_max(P, pk_sub_sat((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x114, 0xF, 0xF, true), 4 * step2));
+    P = pk_max(P, pk_sub_sat((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x118, 0xF, 0xF, true), 8 * step2));
+    P = pk_max(P, pk_sub_sat((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x142, 0xF, 0xF, true), w15_2));
+    P = pk_max(P, pk_sub_sat((uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x143, 0xF, 0xF, true), w31c_2));
+    return P;
+}
+
 // {a.lo, b.lo} -> (a.lo | b.lo << 16);  {a.hi, b.hi} -> (a.hi | b.hi << 16)
 __device__ __forceinline__ uint32_t pk_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 __device__ __forceinline__ uint32_t pk_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
@@ -76,7 +93,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
     const uint32_t step = K * e;
     const uint32_t step2 = pack16(step);
     const uint32_t w15_2 = pack16(((lane & 15u) + 1u) * step);
-    const uint32_t w31_2 = pack16(lane >= 32u ? (lane - 31u) * step : 0u);  // only lanes >= 32 receive the row_bcast:31 value
+    const uint32_t w31_2 = pack16(lane >= 32u ? (lane - 31u) * step : 0xFFFFu);  // only lanes >= 32 receive the row_bcast:31 value (complemented scan: INF keeps the others out)
     const uint32_t lane_off2 = pack16(K * lane * e);
     const uint32_t c_lo = K * lane, c_hi = QW + K * lane;
     const bool act_lo = c_lo < pitch, act_hi = c_hi < pitch;  // my 8 columns of the quad lie inside the plane row
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
         auto row_body = [&](const uint32_t (&PM)[K], const uint32_t (&PD)[K]) {
             uint32_t (&Mc)[K] = Mout;
             uint32_t (&Dc)[K] = Dout;
-            uint32_t Ic[K], PDe[K];
+            uint32_t Ic[K], PDe[K], fDv[K];   // fDv: flag D == PD + e, per half
             const uint32_t de_row2 = (meta.flags & ROW_END) ? eend2 : de2;
 #pragma unroll
             for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], de_row2);
@@ -154,6 +171,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     Dc[k] = PDe[k];
                     Mc[k] = pk_min(PM[k], Dc[k]);
                     Ic[k] = INF2;
+                    fDv[k] = 0x00010001u;
                 }
             } else {
                 // insertion-open rule, branch-free: "always" == the child symbol 0, which no query symbol equals
@@ -180,25 +198,50 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) mI[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ csym2)));
                 }
-                uint32_t Hc[K];
-                uint32_t pm_left = PMl;
+                // The eight columns of a lane are independent until the insertion chain, and gfx950 wants a wait state between
+                // a packed-math result and a packed-math use of it: the recurrences are therefore written one OPERATION at a
+                // time over all eight columns (the scheduler is told not to move instructions across the steps), so that a
+                // dependent pair is seven instructions apart instead of adjacent (~45 s_nop per row otherwise).
+                uint32_t Hc[K], u[K], h1[K];
                 // (mis)match cost of the column to the left: x where its symbol differs, 0 on a match (x -sat 0xFFFF)
-                uint32_t cost_left = pk_sub_sat(x2, pku(pkv(0u) - pkv(pk_is_zero(qlE ^ sym2))));
-                uint32_t t = INF2;  // in-lane insertion chain, both quads at once
+                const uint32_t cost_left0 = pk_sub_sat(x2, pku(pkv(0u) - pkv(pk_is_zero(qlE ^ sym2))));
+#pragma unroll
+                for (int k = 0; k < K; ++k) u[k] = pk_add_sat(PM[k], doe2);
+                h1[0] = cost_left0;
+#pragma unroll
+                for (int k = 1; k < K; ++k) h1[k] = pk_sub_sat(x2, mD[k - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) u[k] = pk_max(u[k], mD[k]);   // D: open a deletion only where the symbols differ (or past the query end, where q is 0)
+                h1[0] = pk_add_sat(PMl, h1[0]);
+#pragma unroll
+                for (int k = 1; k < K; ++k) h1[k] = pk_add_sat(PM[k - 1], h1[k]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) Dc[k] = pk_min(PDe[k], u[k]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) Hc[k] = pk_min(h1[k], Dc[k]);
+                Hc[0] &= start_keep;  // H[start][0] = 0
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) u[k] = pk_add_sat(Hc[k], ioe2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) u[k] = pk_max(u[k], mI[k]);   // insertion open: A = (q != child symbol) ? H + oe : INF
+                __builtin_amdgcn_sched_barrier(0);
+                // in-lane insertion chain, both quads at once; the deletion flag (independent of it) fills its wait states
+                uint32_t t = INF2;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    // D: open a deletion only where the symbols differ (or past the query end, where q is 0)
-                    Dc[k] = pk_min(PDe[k], pk_max(pk_add_sat(PM[k], doe2), mD[k]));
-                    Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
-                    if (k == 0) Hc[k] &= start_keep;  // H[start][0] = 0
-                    pm_left = PM[k];
-                    cost_left = pk_sub_sat(x2, mD[k]);
-                    // insertion open: A = (q != child symbol) ? H + oe : INF
-                    const uint32_t a = pk_max(pk_add_sat(Hc[k], ioe2), mI[k]);
+                    const uint32_t te = pk_add_sat(t, e2);
+                    const uint32_t dd = pk_sub_sat(PDe[k], Dc[k]);
                     Ic[k] = t;
-                    t = pk_min(pk_add_sat(t, e2), a);
+                    t = pk_min(te, u[k]);
+                    fDv[k] = pk_sub_sat(0x00010001u, dd);
                 }
-                const uint32_t Pm = wave_scan_min_plus_pk(t, step2, w15_2, w31_2);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t Pm = ~wave_scan_max_minus_pk(~t, step2, w15_2, w31_2);
                 const uint32_t excl = pk_wave_shr1(Pm, INF2);
                 // carry entering quad 1 = everything that leaves quad 0 (nothing enters quad 0: single strip)
                 const uint32_t total_lo = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63) & 0xFFFFu;
@@ -217,7 +260,7 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t fA = pk_eq_ge(Ic[k], Mc[k]), fC = pk_eq_ge(Dc[k], Mc[k]);
-                const uint32_t fB = pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]), fD = pk_eq_ge(PDe[k], Dc[k]);
+                const uint32_t fB = pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]), fD = fDv[k];
                 if (MF == 2) {
                     Ms[k] = (fC << 15) | ((fA << 14) | ((fD << 13) | ((fB << 12) | pk_min(Mc[k], 0x0FFF0FFFu))));
                 } else if (MF == 1) {
