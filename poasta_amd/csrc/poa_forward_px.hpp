@@ -108,9 +108,11 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
 
     // Symbol masks per lane, staged once in LDS: mask[s][k] = 0xFFFF per half where my query symbol equals symbol s
     // ("ACGT"[s]).  A row then fetches the masks of its symbol and of its child symbol
-    // (4 ds_read_b128) instead of recomputing them (7 VALU instructions per register).  Other symbols: computed.
-    __shared__ uint4 sym_tab[4 * 4 * 2 * 64];  // 32 KB per block of four waves: five blocks per CU
-    uint4* my_tab = sym_tab + (threadIdx.x >> 6) * (4 * 2 * 64) + lane;
+    // (4 ds_read_b128) instead of recomputing them (7 VALU instructions per register).  A fifth, all-zero table stands for
+    // "no child symbol: an insertion opens everywhere", so that the common row takes one branch for both masks.  Other
+    // symbols: computed.
+    __shared__ uint4 sym_tab[4 * 5 * 2 * 64];  // 40 KB per block of four waves: four blocks per CU (what the registers allow anyway)
+    uint4* my_tab = sym_tab + (threadIdx.x >> 6) * (5 * 2 * 64) + lane;
     {
         const uint32_t letters[4] = {'A', 'C', 'G', 'T'};
 #pragma unroll
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
             my_tab[(si * 2 + 0) * 64] = make_uint4(m[0], m[1], m[2], m[3]);
             my_tab[(si * 2 + 1) * 64] = make_uint4(m[4], m[5], m[6], m[7]);
         }
+        my_tab[(4 * 2 + 0) * 64] = make_uint4(0u, 0u, 0u, 0u);
+        my_tab[(4 * 2 + 1) * 64] = make_uint4(0u, 0u, 0u, 0u);
         // each lane reads back only what it wrote itself: no barrier needed
     }
 
@@ -180,23 +184,18 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                 // masks (0xFFFF per half): mD where my query symbol equals the row's symbol, mI where it equals the child symbol
                 uint32_t mD[K], mI[K];
                 const uint32_t si = meta.sym_idx & 15u, ci = meta.sym_idx >> 4;  // set by build_flat_graph
-                if (si < 4) {
+                if ((meta.sym_idx & 0x88u) == 0) {   // both symbols among ACGT (or no child symbol, table 4): the common row
                     const uint4 a = my_tab[(si * 2 + 0) * 64], b = my_tab[(si * 2 + 1) * 64];
+                    const uint4 c = my_tab[(ci * 2 + 0) * 64], d = my_tab[(ci * 2 + 1) * 64];
                     mD[0] = a.x; mD[1] = a.y; mD[2] = a.z; mD[3] = a.w; mD[4] = b.x; mD[5] = b.y; mD[6] = b.z; mD[7] = b.w;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) mD[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ sym2)));
-                }
-                if (ci == 4) {  // no child symbol to spare: open everywhere
-#pragma unroll
-                    for (int k = 0; k < K; ++k) mI[k] = 0u;
-                } else if (ci < 4) {
-                    const uint4 a = my_tab[(ci * 2 + 0) * 64], b = my_tab[(ci * 2 + 1) * 64];
-                    mI[0] = a.x; mI[1] = a.y; mI[2] = a.z; mI[3] = a.w; mI[4] = b.x; mI[5] = b.y; mI[6] = b.z; mI[7] = b.w;
+                    mI[0] = c.x; mI[1] = c.y; mI[2] = c.z; mI[3] = c.w; mI[4] = d.x; mI[5] = d.y; mI[6] = d.z; mI[7] = d.w;
                 } else {
                     const uint32_t csym2 = cs1 | (cs1 << 16);
 #pragma unroll
-                    for (int k = 0; k < K; ++k) mI[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ csym2)));
+                    for (int k = 0; k < K; ++k) {
+                        mD[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ sym2)));
+                        mI[k] = pku(pkv(0u) - pkv(pk_is_zero(qP[k] ^ csym2)));
+                    }
                 }
                 // The eight columns of a lane are independent until the insertion chain, and gfx950 wants a wait state between
                 // a packed-math result and a packed-math use of it: the recurrences are therefore written one OPERATION at a

@@ -133,7 +133,7 @@ int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
         if (has_end_child || multi) m.flags |= ROW_OPENI_ALWAYS;
         else if (!has_real) m.flags |= ROW_OPENI_NEVER;
         {
-            auto idx = [](uint8_t c) -> uint8_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 5; };
+            auto idx = [](uint8_t c) -> uint8_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 8; };
             const uint8_t ci = (m.flags & ROW_OPENI_ALWAYS) ? 4 : idx(m.child_sym);
             m.sym_idx = (uint8_t)(idx(m.sym) | (ci << 4));
         }

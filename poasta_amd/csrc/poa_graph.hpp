@@ -64,7 +64,8 @@ struct RowMeta {  // 16 bytes, one per row
     uint8_t sym;
     uint8_t child_sym;    // common symbol of the non-end children (valid unless ALWAYS/NEVER)
     uint8_t flags;
-    uint8_t sym_idx;      // low nibble: index of sym in "ACGT" (5: other); high nibble: same for child_sym (4: none / open always)
+    uint8_t sym_idx;      // low nibble: index of sym in "ACGT" (8: other); high nibble: same for child_sym (4: none / open always);
+                          // (sym_idx & 0x88) == 0: both masks of the row come from the one-strip kernel's LDS tables
 };
 static_assert(sizeof(RowMeta) == 16, "RowMeta layout");
 
