@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void poa_forward_px_kernel(FwdParams P) {
                     Ic[k] = t;
                     t = pk_min(te, u[k]);
                     fDv[k] = pk_sub_sat(0x00010001u, dd);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 const uint32_t Pm = ~wave_scan_max_minus_pk(~t, step2, w15_2, w31_2);
                 const uint32_t excl = pk_wave_shr1(Pm, INF2);
                 // carry entering quad 1 = everything that leaves quad 0 (nothing enters quad 0: single strip)
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
     const uint32_t step = K * e;
     const uint32_t step2 = pack16(step);
     const uint32_t w15_2 = pack16(((lane & 15u) + 1u) * step);
-    const uint32_t w31_2 = pack16(lane >= 32u ? (lane - 31u) * step : 0u);
+    const uint32_t w31_2 = pack16(lane >= 32u ? (lane - 31u) * step : 0xFFFFu);  // (complemented scan: INF keeps the lower lanes out)
     const uint32_t lane_off2 = pack16(K * lane * e);
     const uint32_t n_strips = (pitch + W - 1) / W;
     const uint32_t n_groups = (n_strips + S - 1) / S;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
             auto row_body = [&](const uint32_t (&PM)[K], const uint32_t (&PD)[K]) {
                 uint32_t (&Mc)[K] = Mout;
                 uint32_t (&Dc)[K] = Dout;
-                uint32_t Ic[K], PDe[K];
+                uint32_t Ic[K], PDe[K], fDv[K];   // fDv: flag D == PD + e, per half
                 const uint32_t de_row2 = (meta.flags & ROW_END) ? eend2 : de2;
 #pragma unroll
                 for (int k = 0; k < K; ++k) PDe[k] = pk_add_sat(PD[k], de_row2);
@@ -488,28 +488,67 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                         Dc[k] = PDe[k];
                         Mc[k] = pk_min(PM[k], Dc[k]);
                         Ic[k] = INF2;
+                        fDv[k] = 0x00010001u;
                     }
                 } else {
                     const uint32_t cs1 = (meta.flags & ROW_OPENI_ALWAYS) ? 0u : (uint32_t)meta.child_sym;
                     const uint32_t csym2 = cs1 | (cs1 << 16);
                     const uint32_t start_keep = ((meta.flags & ROW_START) && sbase == 0 && lane == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
-                    uint32_t Hc[K];
-                    uint32_t pm_left = PMl;
-                    uint32_t cost_left = pk_sub_sat(x2, pk_shl<8>(pk_is_zero(qlE ^ sym2)));
-                    uint32_t t = INF2;
+                    // one operation at a time over the eight columns, as in poa_forward_px_kernel (no wait states between a
+                    // packed result and its packed use); here the symbol masks are computed, the LDS holds the ring
+                    uint32_t Hc[K], u[K], h1[K], mD[K], mI[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { mD[k] = qP[k] ^ sym2; mI[k] = qP[k] ^ csym2; }
+                    h1[0] = qlE ^ sym2;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { mD[k] = pk_is_zero(mD[k]); mI[k] = pk_is_zero(mI[k]); }   // 1 where the symbols are equal
+                    h1[0] = pk_is_zero(h1[0]);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) u[k] = pk_add_sat(PM[k], doe2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { mD[k] = pku(pkv(0u) - pkv(mD[k])); mI[k] = pku(pkv(0u) - pkv(mI[k])); }   // 0xFFFF where equal
+                    h1[0] = pku(pkv(0u) - pkv(h1[0]));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) u[k] = pk_max(u[k], mD[k]);   // D: open a deletion only where the symbols differ
+                    h1[0] = pk_sub_sat(x2, h1[0]);
+#pragma unroll
+                    for (int k = 1; k < K; ++k) h1[k] = pk_sub_sat(x2, mD[k - 1]);   // (mis)match cost of the column to the left
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) Dc[k] = pk_min(PDe[k], u[k]);
+                    h1[0] = pk_add_sat(PMl, h1[0]);
+#pragma unroll
+                    for (int k = 1; k < K; ++k) h1[k] = pk_add_sat(PM[k - 1], h1[k]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) Hc[k] = pk_min(h1[k], Dc[k]);
+                    Hc[0] &= start_keep;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) u[k] = pk_add_sat(Hc[k], ioe2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) u[k] = pk_max(u[k], mI[k]);   // insertion open: (q != child symbol) ? H + oe : INF
+                    __builtin_amdgcn_sched_barrier(0);
+                    uint32_t t = INF2;   // in-lane insertion chain; the deletion flag fills its wait states
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const uint32_t eq1 = pk_is_zero(qP[k] ^ sym2);
-                        Dc[k] = pk_min(PDe[k], pk_inf_where(pk_add_sat(PM[k], doe2), eq1));
-                        Hc[k] = pk_min(pk_add_sat(pm_left, cost_left), Dc[k]);
-                        if (k == 0) Hc[k] &= start_keep;
-                        pm_left = PM[k];
-                        cost_left = pk_sub_sat(x2, pk_shl<8>(eq1));
-                        const uint32_t a = pk_inf_where(pk_add_sat(Hc[k], ioe2), pk_is_zero(qP[k] ^ csym2));
+                        const uint32_t te = pk_add_sat(t, e2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        uint32_t dd = pk_sub_sat(PDe[k], Dc[k]);
+                        asm volatile("" : "+v"(dd));   // (keeps the flag arithmetic here: it would otherwise sink to its use)
+                        __builtin_amdgcn_sched_barrier(0);
                         Ic[k] = t;
-                        t = pk_min(pk_add_sat(t, e2), a);
+                        t = pk_min(te, u[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fDv[k] = pk_sub_sat(0x00010001u, dd);
+                        asm volatile("" : "+v"(fDv[k]));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    const uint32_t Pm = wave_scan_min_plus_pk(t, step2, w15_2, w31_2);
+                    const uint32_t Pm = ~wave_scan_max_minus_pk(~t, step2, w15_2, w31_2);
                     const uint32_t excl = pk_wave_shr1(Pm, INF2);
                     const uint32_t totals = (uint32_t)__builtin_amdgcn_readlane((int)Pm, 63);
                     // scan carries: into quad 0 from the previous strip, into quad 1 from quad 0, out of quad 1 to the next strip
@@ -534,7 +573,7 @@ __global__ __launch_bounds__(1024) void poa_forward_pxmw_kernel(FwdParams P) {
                     accA |= pk_eq_ge(Ic[k], Mc[k]) << k;
                     accB |= pk_eq_ge(pk_add_sat(i_left, e2), Ic[k]) << k;
                     accC |= pk_eq_ge(Dc[k], Mc[k]) << k;
-                    accD |= pk_eq_ge(PDe[k], Dc[k]) << k;
+                    accD |= fDv[k] << k;
                     i_left = Ic[k];
                 }
                 const uint32_t ab = __builtin_amdgcn_perm(accB, accA, 0x06020400u);
