@@ -251,11 +251,17 @@ def main():
         if valu_insts and ceil_simd:
             ach = valu_insts / (avg_launch_ms * 1e-3) / 1e9
             peak = ceil_simd * N_SIMD / 1e9
+            salu_insts = kc.get("sq_insts_salu_per_launch")
             roof.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
-                         "note": "VALU issue binds this kernel: achieved = SQ_INSTS_VALU per launch (PMC, profiles/kernel_counters.json) / "
+                         "insts_per_cell": {"valu": round(valu_insts * 64 / cells_per_launch, 3),
+                                            "salu": None if not salu_insts else round(salu_insts * 64 / cells_per_launch, 3)},
+                         "note": "Instruction issue binds this kernel: achieved = SQ_INSTS_VALU per launch (PMC, profiles/kernel_counters.json) / "
                                  "launch time; peak = measured issue rate of the packed-u16 / permute / DPP instructions it consists of, "
-                                 "8 waves per SIMD (profiles/microbench).  HBM beside it: alg_* is SURVEY.md 8(d)'s fixed 12 B/cell "
-                                 "(the engine stores ~2.7 B/cell, so that ratio exceeds 1 by construction), traffic* are PMC bytes"})
+                                 "8 waves per SIMD (profiles/microbench).  The SALU instructions and wait states of a row take issue slots "
+                                 "too (occupancy sweep, profiles/r02b_px_mf4: 0.625 us per wave and 1024-cell row at saturation), so fewer "
+                                 "instructions per cell make the kernel faster and this fraction smaller.  HBM beside it: alg_* is "
+                                 "SURVEY.md 8(d)'s fixed 12 B/cell (the engine stores ~2.4 B/cell, so that ratio exceeds 1 by construction), "
+                                 "traffic* are PMC bytes"})
         else:
             roof.update({"bound": "hbm", "achieved": round(alg_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(alg_achieved / HBM_PEAK_GBPS, 4),
