@@ -46,13 +46,9 @@ __device__ __forceinline__ uint32_t tp_sat(uint32_t a, uint32_t b) {
 }
 
 // inclusive min-plus scan over the lanes with a constant decay per lane step: out(l) = min over l' <= l of v(l') + (l - l') * step
+// (DPP row shifts and broadcasts, no LDS pipe: wave_scan_min_plus of the one-piece kernels)
 __device__ __forceinline__ uint32_t tp_scan(uint32_t v, uint32_t step, uint32_t lane) {
-#pragma unroll
-    for (uint32_t s = 1; s < 64; s <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, (int)s, 64);
-        if (lane >= s) v = min(v, tp_sat(t, s * step));
-    }
-    return v;
+    return wave_scan_min_plus(v, step, ((lane & 15u) + 1u) * step, (lane - 31u) * step);
 }
 
 // Four consecutive columns per lane, 256 columns per pass: every plane access is one 16-byte load / store per lane, 1 KiB
@@ -96,9 +92,8 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
                     pd2[0] = min(pd2[0], c.x); pd2[1] = min(pd2[1], c.y); pd2[2] = min(pd2[2], c.z); pd2[3] = min(pd2[3], c.w);
                 }
             // M of the predecessors one column to the left of my first column
-            uint32_t pml = (uint32_t)__shfl_up((int)pm[K - 1], 1, 64);
-            if (lane == 0) pml = cpm;
-            cpm = (uint32_t)__shfl((int)pm[K - 1], 63, 64);
+            const uint32_t pml = wave_shr1(pm[K - 1], cpm);   // lane 0: the last column of the previous pass
+            cpm = (uint32_t)__builtin_amdgcn_readlane((int)pm[K - 1], 63);
             uint32_t h[K], d1[K], d2[K], a[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -130,13 +125,12 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
             for (int k = 1; k < K; ++k) v1[k] = min(tp_sat(v1[k - 1], P.e1), a[k - 1]);
             const uint32_t out1 = min(tp_sat(v1[K - 1], P.e1), a[K - 1]);   // leaves my last column towards the next lane
             const uint32_t s1 = tp_scan(out1, K * P.e1, lane);
-            uint32_t in1 = (uint32_t)__shfl_up((int)s1, 1, 64);
-            if (lane == 0) in1 = INF;
+            uint32_t in1 = wave_shr1(s1, INF);
             in1 = min(in1, tp_sat(c1, lane * K * P.e1));
             if (ps == 0 && lane == 0) in1 = INF;                            // I1[v][0] = INF
 #pragma unroll
             for (int k = 0; k < K; ++k) v1[k] = min(v1[k], tp_sat(in1, (uint32_t)k * P.e1));
-            c1 = min((uint32_t)__shfl((int)s1, 63, 64), tp_sat(c1, 64 * K * P.e1));
+            c1 = min((uint32_t)__builtin_amdgcn_readlane((int)s1, 63), tp_sat(c1, 64 * K * P.e1));
             // I2 over the finished I1: I2[c] = min(I1[c-1], I2[c-1]) + e2
             const uint32_t i1_left = in1;                                    // == I1 of my first column
             uint32_t v2[K];
@@ -145,14 +139,13 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
             for (int k = 1; k < K; ++k) v2[k] = tp_sat(min(v2[k - 1], v1[k - 1]), P.e2);
             const uint32_t out2 = tp_sat(min(v2[K - 1], v1[K - 1]), P.e2);
             const uint32_t s2 = tp_scan(out2, K * P.e2, lane);
-            uint32_t in2 = (uint32_t)__shfl_up((int)s2, 1, 64);
-            if (lane == 0) in2 = INF;
+            uint32_t in2 = wave_shr1(s2, INF);
             in2 = min(in2, tp_sat(c2, lane * K * P.e2));
             if (ps == 0 && lane == 0) in2 = INF;
             (void)i1_left;
 #pragma unroll
             for (int k = 0; k < K; ++k) v2[k] = min(v2[k], tp_sat(in2, (uint32_t)k * P.e2));
-            c2 = min((uint32_t)__shfl((int)s2, 63, 64), tp_sat(c2, 64 * K * P.e2));
+            c2 = min((uint32_t)__builtin_amdgcn_readlane((int)s2, 63), tp_sat(c2, 64 * K * P.e2));
             if (is_end) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) { v1[k] = INF; v2[k] = INF; }
