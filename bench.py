@@ -139,17 +139,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(b, k, cfg=None):
-        """k steps on batch b between barriers -> (seconds max over ranks, engine stats of those steps)."""
-        barrier()
+    def timed(b, k, cfg=None, collective=True):
+        """k steps on batch b between barriers -> (seconds max over ranks, engine stats of those steps).
+        collective=False: this rank alone (the extras below must not be able to hang the job if one rank cannot run them)."""
+        if collective:
+            barrier()
+        else:
+            torch.cuda.synchronize()
         b.stats()
         t_start = time.perf_counter()
         for _ in range(k):
             b.run(costs, stream, cfg)
-        barrier()
+        if collective:
+            barrier()
+        else:
+            torch.cuda.synchronize()
         el = time.perf_counter() - t_start
         st_ = b.stats()  # HIP events recorded on `stream` around every kernel of the timed steps
-        if dist is not None:
+        if dist is not None and collective:
             t = torch.tensor([el], dtype=torch.float64, device=torch.device("cpu") if args.rehearse else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -203,21 +210,23 @@ def main():
 
     # ---- the same step with u32 planes: 12 real bytes per cell (rank-local, not part of `value`) ----
     like = None
-    if not args.no_extras and "POA_PLANES" not in os.environ:
+    if not args.no_extras and not args.rehearse and "POA_PLANES" not in os.environ:   # (a rehearsal's ranks share one GPU: 2 x 123 GB of u32 planes do not fit)
         os.environ["POA_PLANES"] = "32"
         try:
             b32 = aligner.ResidentBatch(graph, qseq, qoff, device=local_rank)
             b32.run(costs, stream)
-            el32, st32 = timed(b32, 2)
+            el32, st32 = timed(b32, 2, collective=False)
             l32 = max(st32["n_forward_launches"], 1)
             ms32 = st32["ms_forward"] / l32
             cpl32 = cells_rank * st32["n_runs"] / l32
-            like = {"dtype": "u32", "value": round(cells_rank * world * 2 / el32 / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(el32 / 2 * 1e3, 3),
+            like = {"dtype": "u32", "value": round(cells_rank * 2 / el32 / 1e9, 3), "unit": "Gcells/s (this rank)", "ms_per_step": round(el32 / 2 * 1e3, 3),
                     "forward_launch_ms": round(ms32, 3), "hbm_bytes_written_per_cell": 12,
                     "hbm_achieved_GBps": round(12.0 * cpl32 / (ms32 * 1e-3) / 1e9, 1),
                     "hbm_frac": round(12.0 * cpl32 / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "note": "POA_PLANES=32: M, I, D stored as u32 = the reference's VisitedCellAffine; here the 12 B/cell of SURVEY.md 8(d) are real stores"}
             b32.close()
+        except Exception as exc:   # an extra never fails the bench (e.g. no room for a second, 123 GB workspace)
+            like = {"error": "%s: %s" % (type(exc).__name__, exc)}
         finally:
             del os.environ["POA_PLANES"]
 
