@@ -18,6 +18,7 @@ Rank 0 prints ONE JSON line (task contract) with
                 12 B/cell accounting, `traffic*` = PMC bytes;
   like_for_like the same step with u32 score planes (12 real bytes per cell: where §8(d)'s accounting is physical);
   value_incl_d2h  the step including the device->host copy of scores, flags and pairs (SURVEY.md §8(d)'s wall time);
+  steps_in_flight the same step with three resident batches round robin on three HIP streams (traceback under the next forward pass);
   bit_exact     (N = 1) the hybrid mode — dense pass + replay of the reference's search for every query the dense pass
                 could not certify — over the whole batch: throughput and how many alignments equal the restated
                 reference's;
@@ -208,6 +209,40 @@ def main():
     else:
         res = batch.fetch(want_pairs=(rank == 0))
 
+    # ---- steps in flight: three resident batches on three HIP streams, round robin (rank-local, not part of `value`):
+    #      the traceback of a step (latency bound, few issue slots) runs under the forward pass of the next ----
+    piped = None
+    if not args.no_extras and not args.rehearse and "POA_PLANES" not in os.environ:
+        try:
+            depth = 3
+            # (each batch gets what the compact layout needs, not the u32-sized default, so that three fit beside the first)
+            ws = int(3.2 * cells_rank) + (1 << 30)
+            pb = [aligner.ResidentBatch(graph, qseq, qoff, device=local_rank, workspace_bytes=ws) for _ in range(depth)]
+            ps = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+            for k in range(2 * depth):
+                pb[k % depth].run(costs, ps[k % depth].cuda_stream)
+            torch.cuda.synchronize()
+            n_p = max(12, args.steps)
+            t1 = time.perf_counter()
+            for k in range(n_p):
+                pb[k % depth].run(costs, ps[k % depth].cuda_stream)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t1
+            chunks_p = pb[0].stats()["n_chunks"]
+            same = True
+            for b_ in pb:
+                r_ = b_.fetch(want_pairs=True)
+                same = same and np.array_equal(r_.score, res.score) and np.array_equal(r_.pairs, res.pairs) and np.array_equal(r_.flags, res.flags)
+                b_.close()
+            piped = {"in_flight": depth, "steps": n_p, "value": round(cells_rank * n_p / dtp / 1e9, 3), "unit": "Gcells/s (this rank)",
+                     "ms_per_step": round(dtp / n_p * 1e3, 3), "chunks_per_step": chunks_p, "results_equal_the_timed_steps": bool(same),
+                     "note": "the same step, three resident batches round robin on three HIP streams: a step's traceback overlaps the next "
+                             "step's forward pass (how a driver with batches to spare would call poa_batch_run)"}
+        except Exception as exc:
+            piped = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        from poasta_amd import _lib as _plib
+        _plib.lib().poa_release_cache()   # the workspaces just closed go back to the device before the next extra allocates
+
     # ---- the same step with u32 planes: 12 real bytes per cell (rank-local, not part of `value`) ----
     like = None
     if not args.no_extras and not args.rehearse and "POA_PLANES" not in os.environ:   # (a rehearsal's ranks share one GPU: 2 x 123 GB of u32 planes do not fit)
@@ -298,6 +333,8 @@ def main():
             line["like_for_like"] = like
         if incl_d2h is not None:
             line["value_incl_d2h"] = incl_d2h
+        if piped is not None:
+            line["steps_in_flight"] = piped
         if world == 1 and args.cpu_sample != 0 and not args.no_extras:
             n_cpu = len(qs) if args.cpu_sample < 0 else min(args.cpu_sample, len(qs))
             line["cpu_baseline"], A = cpu_baseline(graph, qs[:n_cpu], n_rows)
