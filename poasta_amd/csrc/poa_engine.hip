@@ -784,7 +784,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
 
         if (!(fuse_tb && !relative && max_pitch <= 1024 && (!compact || packed))) {
             // four walks per wave only when one walk per wave would exceed the chip's wave slots (256 CUs x 32)
-            const int tbg = (getenv("POA_TB_GROUP") || ch.count > 8192) ? tb_group : 64;
+            const int tbg = (getenv("POA_TB_GROUP") || ch.count > 4096) ? tb_group : 64;   // measured: 4 096 walks 1.13 vs 1.17 ms, 8 192 walks 1.90 vs 1.41 ms (64 vs 16 lanes)
             if (compact && tbg == 16) {
                 TbParams tp16 = tp;
                 if (!getenv("POA_TB_DEPTH")) tp16.spec_depth = 16;
@@ -1220,19 +1220,26 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
         return POA_OK;
     }
     const uint32_t pitch = (uint32_t)((max_len + 64) & ~63ull);
-    const uint64_t per_query = 5ull * fg.n * pitch;   // u32 elements
+    const uint64_t per_query = 5ull * fg.n * pitch;   // plane elements
     if (per_query >= (1ull << 34)) return fail(POA_ERR_UNSUPPORTED, "two-piece pass: planes of one query too large");
+    // u16 planes under the bound of the one-piece pass (poa_batch_run_ex) taken with the first piece's costs: a gap never
+    // costs more than its first-piece price, so [o1 + e1 L] + [o1 + e1 (shortest path)] bounds the optimum here too
+    const uint64_t ub = (max_len ? (uint64_t)costs->gap_open1 + (uint64_t)costs->gap_extend1 * max_len : 0) +
+                        (fg.min_path_nodes ? (uint64_t)costs->gap_open1 + (uint64_t)costs->gap_extend1 * fg.min_path_nodes : 0);
+    bool narrow = ub <= 65534;
+    if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
+    const uint64_t elem = narrow ? 2 : 4;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget = std::min<uint64_t>((uint64_t)(free_b * 0.6), 64ull << 30);
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_queries, budget / (per_query * 4 + 1)));
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_queries, budget / (per_query * elem + 1)));
     const uint32_t stride = (uint32_t)std::min<uint64_t>(fg.n + max_len + 1, 0xFFFFFFFFull);
     DevBuf<RowMeta> d_rows; DevBuf<uint32_t> d_pred, d_planes, d_score, d_flags, d_np; DevBuf<uint8_t> d_q; DevBuf<uint64_t> d_qoff;
     DevBuf<poa_aln_pair_t> d_scratch;
     HIP_TRY(d_rows.alloc(fg.rows.size())); HIP_TRY(d_pred.alloc(std::max<size_t>(fg.pred_rows.size(), 1)));
     HIP_TRY(d_q.alloc(std::max<uint64_t>(qoff[n_queries], 1))); HIP_TRY(d_qoff.alloc(n_queries + 1));
     HIP_TRY(d_score.alloc(n_queries)); HIP_TRY(d_flags.alloc(n_queries)); HIP_TRY(d_np.alloc(n_queries));
-    if (d_planes.alloc((size_t)chunk * per_query) != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, "two-piece pass: plane workspace");
+    if (d_planes.alloc((size_t)((chunk * per_query * elem + 3) / 4)) != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, "two-piece pass: plane workspace");
     HIP_TRY(d_scratch.alloc((size_t)chunk * stride));
     HIP_TRY(hipMemcpy(d_rows.p, fg.rows.data(), fg.rows.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
     if (!fg.pred_rows.empty()) HIP_TRY(hipMemcpy(d_pred.p, fg.pred_rows.data(), fg.pred_rows.size() * 4, hipMemcpyHostToDevice));
@@ -1255,10 +1262,13 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
         const uint32_t cnt = std::min(chunk, n_queries - first);
         P.first_query = first; P.n_queries = cnt;
         HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(poa2_forward_kernel, dim3(cnt), dim3(64), 0, nullptr, P);
+        // previous row in registers for up to 1024 (u16: two passes of 512) / 1024 (u32: four passes of 256) columns
+        if (narrow) hipLaunchKernelGGL((poa2_forward_kernel<uint16_t, 2>), dim3(cnt), dim3(64), 0, nullptr, P);
+        else hipLaunchKernelGGL((poa2_forward_kernel<uint32_t, 4>), dim3(cnt), dim3(64), 0, nullptr, P);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
-        hipLaunchKernelGGL(poa2_traceback_kernel, dim3((cnt + 63) / 64), dim3(64), 0, nullptr, P);
+        if (narrow) hipLaunchKernelGGL(poa2_traceback_kernel<uint16_t>, dim3((cnt + 63) / 64), dim3(64), 0, nullptr, P);
+        else hipLaunchKernelGGL(poa2_traceback_kernel<uint32_t>, dim3((cnt + 63) / 64), dim3(64), 0, nullptr, P);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e2, nullptr));
         HIP_TRY(hipEventSynchronize(e2));
@@ -1282,9 +1292,16 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
         if (planes_out && first == 0) {
             const uint32_t L0 = (uint32_t)(qoff[1] - qoff[0]);
             std::vector<uint32_t> row(pitch);
+            std::vector<uint16_t> row16(pitch);
             for (int pl = 0; pl < 5; ++pl)
                 for (uint32_t r = 0; r < fg.n; ++r) {
-                    HIP_TRY(hipMemcpy(row.data(), d_planes.p + ((uint64_t)pl * fg.n + r) * pitch, (size_t)pitch * 4, hipMemcpyDeviceToHost));
+                    const uint64_t at_el = ((uint64_t)pl * fg.n + r) * pitch;
+                    if (narrow) {
+                        HIP_TRY(hipMemcpy(row16.data(), reinterpret_cast<const uint16_t*>(d_planes.p) + at_el, (size_t)pitch * 2, hipMemcpyDeviceToHost));
+                        for (uint32_t c = 0; c < pitch; ++c) row[c] = row16[c] == 0xFFFFu ? 0xFFFFFFFFu : row16[c];
+                    } else {
+                        HIP_TRY(hipMemcpy(row.data(), d_planes.p + at_el, (size_t)pitch * 4, hipMemcpyDeviceToHost));
+                    }
                     std::memcpy(planes_out[pl] + (size_t)r * (L0 + 1), row.data(), ((size_t)L0 + 1) * 4);
                 }
         }
@@ -1294,7 +1311,7 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     HIP_TRY(hipMemcpy(h_flags.data(), d_flags.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
     if (flags) std::memcpy(flags, h_flags.data(), (size_t)n_queries * 4);
     if (stats) {
-        stats->cells = cells; stats->bases = qoff[n_queries]; stats->plane_bytes = cells * 20; stats->n_queries = n_queries;
+        stats->cells = cells; stats->bases = qoff[n_queries]; stats->plane_bytes = cells * 5 * elem; stats->n_queries = n_queries;
         stats->n_chunks = n_chunks; stats->n_forward_launches = n_chunks; stats->ms_forward = ms_f; stats->ms_traceback = ms_t;
         uint32_t nf = 0;
         for (uint32_t i = 0; i < n_queries; ++i) nf += h_flags[i] != 0;

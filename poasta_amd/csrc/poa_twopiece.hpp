@@ -31,7 +31,7 @@ struct TwoPieceParams {
     const uint64_t* qoff;
     uint32_t first_query, n_queries;   // chunk
     uint32_t pitch;                    // columns per row (multiple of 64), same for the whole chunk
-    uint32_t* planes;                  // per slot: [5][n_rows][pitch]: M, I1, D1, I2, D2
+    uint32_t* planes;                  // per slot: [5][n_rows][pitch] of the kernel's plane type (u32, or u16 when every score that matters fits): M, I1, D1, I2, D2
     uint32_t x, oe, e1, e2, o1;
     uint32_t* score;                   // [total]
     uint32_t* flags;                   // [total]
@@ -51,11 +51,18 @@ __device__ __forceinline__ uint32_t tp_scan(uint32_t v, uint32_t step, uint32_t 
     return wave_scan_min_plus(v, step, ((lane & 15u) + 1u) * step, (lane - 31u) * step);
 }
 
-// Four consecutive columns per lane, 256 columns per pass: every plane access is one 16-byte load / store per lane, 1 KiB
-// contiguous per wave-instruction; the insertion recurrences run as a 4-step chain in the lane plus one wave scan per
-// pass and plane (I1 with decay 4*e1 per lane, I2 over the finished I1 with decay 4*e2), carries between passes in registers.
+// K consecutive columns per lane (4 with u32 planes, 8 with u16), 64 K columns per pass: every plane access is one 16-byte
+// load / store per lane, 1 KiB contiguous per wave-instruction; the insertion recurrences run as a K-step chain in the lane
+// plus one wave scan per pass and plane (I1 with decay K*e1 per lane, I2 over the finished I1 with decay K*e2), carries
+// between passes in registers.  T = uint16_t (same saturation argument as the one-piece u16 planes: poa_batch_run_ex) halves
+// the bytes of a kernel that lives on its stores; arithmetic is u32 in registers either way (PlaneIO widens 0xFFFF to INF).
+// NP: passes whose previous row stays in registers (rows of up to NP * 64 * K columns): a chain row — one predecessor, the
+// previous row — then reads nothing back from the planes (6 of the 16 bytes of traffic per cell with u16 planes).
+template <typename T, int NP>
 __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
-    constexpr int K = 4;
+    using IO = PlaneIO<T>;
+    constexpr int K = IO::K;
+    constexpr uint32_t PW = 64 * K;   // columns per pass
     constexpr uint32_t INF = 0xFFFFFFFFu;
     const uint32_t slot = blockIdx.x, lane = threadIdx.x;
     const uint32_t qi = P.first_query + slot;
@@ -63,17 +70,21 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
     const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
     const uint8_t* q = P.qseq + qbeg;
     const uint64_t plane = (uint64_t)P.n_rows * P.pitch;
-    uint32_t* M = P.planes + (uint64_t)slot * 5 * plane;
-    uint32_t* I1 = M + plane; uint32_t* D1 = I1 + plane; uint32_t* I2 = D1 + plane; uint32_t* D2 = I2 + plane;
-    const uint32_t n_pass = (L + 1 + 255) / 256;   // pitch is a multiple of 64: a pass may end inside the row's padding
+    T* M = reinterpret_cast<T*>(P.planes) + (uint64_t)slot * 5 * plane;
+    T* I1 = M + plane; T* D1 = I1 + plane; T* I2 = D1 + plane; T* D2 = I2 + plane;
+    const uint32_t n_pass = (L + 1 + PW - 1) / PW;   // pitch is a multiple of 64: a pass may end inside the row's padding
+    constexpr int NPA = NP > 0 ? NP : 1;
+    uint32_t keepM[NPA][K], keepD1[NPA][K], keepD2[NPA][K];   // M, D1, D2 of the previous row, my columns of every pass
+    const bool keep = NP > 0 && n_pass <= (uint32_t)NP;
     for (uint32_t r = 0; r < P.n_rows; ++r) {
         const RowMeta rm = P.rows[r];
         const bool is_end = r == P.end_row, is_start = r == P.start_row;
         const uint64_t ro = (uint64_t)r * P.pitch;
         uint32_t c1 = INF, c2 = INF;   // I1 / I2 entering the first column of the pass
         uint32_t cpm = INF;             // min over predecessors of M[p][first column of the pass - 1]
-        for (uint32_t ps = 0; ps < n_pass; ++ps) {
-            const uint32_t j = ps * 256 + K * lane;   // my first column
+        const bool from_regs = keep && r > 0 && (rm.flags & ROW_CHAIN);
+        auto do_pass = [&](const uint32_t ps, uint32_t (&kM)[K], uint32_t (&kD1)[K], uint32_t (&kD2)[K]) {
+            const uint32_t j = ps * PW + K * lane;    // my first column
             const bool in = j < P.pitch;              // (whole 16-byte groups lie inside or outside the plane row)
             uint32_t qs[K], qm;                       // q[j + k] (0 past the end: never a symbol), q[j - 1]
 #pragma unroll
@@ -82,14 +93,16 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
             uint32_t pm[K], pd[K], pd2[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) { pm[k] = INF; pd[k] = INF; pd2[k] = INF; }
-            if (in)
+            if (from_regs) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { pm[k] = kM[k]; pd[k] = kD1[k]; pd2[k] = kD2[k]; }
+            } else if (in)
                 for (uint32_t e = 0; e < rm.pred_count; ++e) {
                     const uint64_t po = (uint64_t)P.pred_rows[rm.pred_begin + e] * P.pitch + j;
-                    const uint4 a = *reinterpret_cast<const uint4*>(M + po), b = *reinterpret_cast<const uint4*>(D1 + po),
-                                c = *reinterpret_cast<const uint4*>(D2 + po);
-                    pm[0] = min(pm[0], a.x); pm[1] = min(pm[1], a.y); pm[2] = min(pm[2], a.z); pm[3] = min(pm[3], a.w);
-                    pd[0] = min(pd[0], b.x); pd[1] = min(pd[1], b.y); pd[2] = min(pd[2], b.z); pd[3] = min(pd[3], b.w);
-                    pd2[0] = min(pd2[0], c.x); pd2[1] = min(pd2[1], c.y); pd2[2] = min(pd2[2], c.z); pd2[3] = min(pd2[3], c.w);
+                    uint32_t a[K], b[K], c[K];
+                    IO::load(M + po, a); IO::load(D1 + po, b); IO::load(D2 + po, c);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { pm[k] = min(pm[k], a[k]); pd[k] = min(pd[k], b[k]); pd2[k] = min(pd2[k], c[k]); }
                 }
             // M of the predecessors one column to the left of my first column
             const uint32_t pml = wave_shr1(pm[K - 1], cpm);   // lane 0: the last column of the previous pass
@@ -157,20 +170,32 @@ __global__ __launch_bounds__(64) void poa2_forward_kernel(TwoPieceParams P) {
                     m[k] = min(h[k], min(v1[k], v2[k]));
                     if (j + k > L) { m[k] = INF; v1[k] = INF; v2[k] = INF; }   // padding columns read as unvisited
                 }
-                *reinterpret_cast<uint4*>(M + ro + j) = make_uint4(m[0], m[1], m[2], m[3]);
-                *reinterpret_cast<uint4*>(I1 + ro + j) = make_uint4(v1[0], v1[1], v1[2], v1[3]);
-                *reinterpret_cast<uint4*>(D1 + ro + j) = make_uint4(d1[0], d1[1], d1[2], d1[3]);
-                *reinterpret_cast<uint4*>(I2 + ro + j) = make_uint4(v2[0], v2[1], v2[2], v2[3]);
-                *reinterpret_cast<uint4*>(D2 + ro + j) = make_uint4(d2[0], d2[1], d2[2], d2[3]);
+                IO::store(M + ro + j, m); IO::store(I1 + ro + j, v1); IO::store(D1 + ro + j, d1);
+                IO::store(I2 + ro + j, v2); IO::store(D2 + ro + j, d2);
+                if (keep) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { kM[k] = m[k]; kD1[k] = d1[k]; kD2[k] = d2[k]; }
+                }
+            } else if (keep) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { kM[k] = INF; kD1[k] = INF; kD2[k] = INF; }
             }
+        };
+        if (keep) {
+#pragma unroll
+            for (int ps = 0; ps < NPA; ++ps)
+                if ((uint32_t)ps < n_pass) do_pass((uint32_t)ps, keepM[ps], keepD1[ps], keepD2[ps]);
+        } else {
+            for (uint32_t ps = 0; ps < n_pass; ++ps) do_pass(ps, keepM[0], keepD1[0], keepD2[0]);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the next rows read this one back (same wave)
     }
-    if (lane == 0) P.score[qi] = M[(uint64_t)P.end_row * P.pitch + L];
+    if (lane == 0) P.score[qi] = IO::get(M + (uint64_t)P.end_row * P.pitch + L);
 }
 
 // One lane per query: the reference's two-piece backtrace on the five planes, every test of a step evaluated so that the
 // certificate (exactly one candidate, no phantom below the target of an open test) can be decided.
+template <typename T>
 __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
     const uint32_t slot = blockIdx.x * 64 + threadIdx.x;
     if (slot >= P.n_queries) return;
@@ -179,9 +204,9 @@ __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
     const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
     const uint8_t* q = P.qseq + qbeg;
     const uint64_t plane = (uint64_t)P.n_rows * P.pitch;
-    const uint32_t* base = P.planes + (uint64_t)slot * 5 * plane;
+    const T* base = reinterpret_cast<const T*>(P.planes) + (uint64_t)slot * 5 * plane;
     enum : uint32_t { SM = 0, SI = 1, SD = 2, SI2 = 3, SD2 = 4 };   // plane order
-    auto S = [&](uint32_t row, uint32_t j, uint32_t st) { return base[st * plane + (uint64_t)row * P.pitch + j]; };
+    auto S = [&](uint32_t row, uint32_t j, uint32_t st) { return PlaneIO<T>::get(base + st * plane + (uint64_t)row * P.pitch + j); };
     const uint32_t INF = 0xFFFFFFFFu;
     poa_aln_pair_t* out = P.scratch + (uint64_t)slot * P.scratch_stride;
     uint32_t n_out = 0, fl = 0;
@@ -200,20 +225,31 @@ __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
         nc = 0; plt = false; pn = false;
         auto sub = [&](uint32_t a, uint32_t b) { const uint32_t r = a - b; if (r == INF) pn = true; return r; };
         auto cand = [&](uint32_t r2, uint32_t j2, uint32_t s2) { if (!first.found) first = Step{r2, j2, s2, true}; nc++; };
+        // every load of a Match-state step on a chain row goes out before the first use: one memory round trip instead of
+        // three (row record -> predecessor list -> predecessor cell); the walk is a chain of such steps
         const uint32_t cs = S(v, j, st);
-        if (cs == INF) return first;
         const RowMeta rm = P.rows[v];
+        uint32_t up = INF, gd = INF, gd2 = INF, gi = INF, gi2 = INF;
+        if (st == SM) {
+            if (v > 0 && j > 0) up = S(v - 1, j - 1, SM);
+            gd = S(v, j, SD); gd2 = S(v, j, SD2); gi = S(v, j, SI); gi2 = S(v, j, SI2);
+        }
+        if (cs == INF) return first;
         if (st == SM) {
             if (j > 0) {
                 const bool moe = sym_eq(v, q[j - 1]);
                 const uint32_t pj = v == P.end_row ? j : j - 1;
                 const uint32_t target = (moe || rm.pred_count == 0) ? cs : sub(cs, P.x);
-                for (uint32_t k = 0; k < rm.pred_count; ++k) { const uint32_t p = P.pred_rows[rm.pred_begin + k]; if (S(p, pj, SM) == target) cand(p, pj, SM); }
+                if ((rm.flags & ROW_CHAIN) && v != P.end_row) {
+                    if (up == target) cand(v - 1, pj, SM);
+                } else {
+                    for (uint32_t k = 0; k < rm.pred_count; ++k) { const uint32_t p = P.pred_rows[rm.pred_begin + k]; if (S(p, pj, SM) == target) cand(p, pj, SM); }
+                }
             }
-            if (S(v, j, SD) == cs) cand(v, j, SD);
-            if (S(v, j, SD2) == cs) cand(v, j, SD2);
-            if (S(v, j, SI) == cs) cand(v, j, SI);
-            if (S(v, j, SI2) == cs) cand(v, j, SI2);
+            if (gd == cs) cand(v, j, SD);
+            if (gd2 == cs) cand(v, j, SD2);
+            if (gi == cs) cand(v, j, SI);
+            if (gi2 == cs) cand(v, j, SI2);
         } else if (st == SD) {
             const uint32_t t_open = sub(sub(cs, P.o1), P.e1), t_ext = sub(cs, P.e1);
             const bool real_open = v != P.end_row && (j >= L || rm.sym != q[j]);
