@@ -22,7 +22,7 @@ for seed in range(args.first, args.first + args.seeds):
     if time.time() - t0 > args.seconds:
         break
     rng = np.random.Generator(np.random.PCG64(77000 + seed))
-    kind = seed % 7
+    kind = seed % 8
     span = None
     if args.verbose:
         print("seed", seed, "kind", kind, file=sys.stderr, flush=True)
@@ -59,6 +59,29 @@ for seed in range(args.first, args.first + args.seeds):
         g, (qseq, qoff) = W.scaled_linearish(nb, int(nb * 0.05), int(nb * 0.025), 4, int(rng.integers(100, 1400)), graph_seed=seed,
                                              query_seed=seed + 1, p_sub=0.05, p_ins=0.02, p_del=0.02)
         qs = [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(4)]
+    elif kind == 7:
+        # a read against a much longer graph, Global: scores beyond u16 in 2-byte cells (relative encoding) or u32 planes,
+        # as the bounds decide; bypass edges and inserted branches make the depth potential's edge terms non-zero
+        nb = int(rng.integers(30000, 42000))
+        from poasta_amd.graph import GraphBuilder
+        b = GraphBuilder()
+        acgt = np.frombuffer(b"ACGT", np.uint8)
+        sym = acgt[rng.integers(0, 4, nb)]
+        ids = b.add_path(sym)
+        for _ in range(int(rng.integers(0, 6))):
+            a = int(rng.integers(0, nb - 500)); b.add_edge(ids[a], ids[a + 2 + int(rng.integers(0, 300))])
+        for _ in range(int(rng.integers(0, 30))):
+            a = int(rng.integers(0, nb - 200)); skip = int(rng.integers(1, 30)); prev = ids[a]
+            for c in acgt[rng.integers(0, 4, skip + int(rng.integers(1, 60)))]:
+                v = b.add_node(int(c)); b.add_edge(prev, v); prev = v
+            b.add_edge(prev, ids[a + skip + 1])
+        for i in rng.choice(np.arange(1, nb - 1), 200, replace=False):
+            v = b.add_node(int(acgt[rng.integers(0, 4)])); b.add_edge(ids[i - 1], v); b.add_edge(v, ids[i + 1])
+        g = b.finish()
+        qs = []
+        for _ in range(4):
+            Lq = int(rng.integers(30, 2600)); a = int(rng.integers(0, nb - Lq))
+            qs.append(W.mutate(rng, sym[a:a + Lq].copy(), 0.05, 0.03, 0.03))
     else:
         # ends-free spans (replayed): random bounds
         alpha = b"ACGT"
