@@ -669,7 +669,8 @@ public:
     POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
         F.kind = 0;
         const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
-        if (C.ends_free || s1 - s0 != 1 || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) return 3;
+        // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341 — so a branching row is fine for it)
+        if (C.ends_free || (s1 - s0 != 1 && (st != EX_ST_I || s1 == s0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) return 3;
         const uint32_t c = gld(&G.succ[s0]);
         Probe P;
         if (!probe_setup(v, j, P, true)) return 3;
