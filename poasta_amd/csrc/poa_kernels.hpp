@@ -83,7 +83,7 @@ struct TbParams {
     uint32_t exact_pass;
     const uint32_t* ex_status;    // [total] 0 ok, 1 reference panic, 2 workspace overflow, 0xFFFFFFFF not replayed
     const uint32_t* ex_end;       // [2 * total] (row, offset) of the end cell the replayed search stopped at
-    uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel<false>),
+    uint32_t code_fmt;            // compact layout: 0 = one nibble per cell, 1 = bit-planes (poa_forward_px_kernel<0>, poa_forward_pxmw_kernel),
                                   // 2 = flags A, C in bits 14, 15 of the stored M value, B, D as bit-planes (poa_forward_px_kernel<1>)
                                   // 3 = flags B, D, A, C in bits 12..15 of the stored M value, no flag words (poa_forward_px_kernel<2>)
     const uint32_t* row_depth;    // relative encoding: stored value = score - e * (row_depth[row] - column); nullptr: absolute
