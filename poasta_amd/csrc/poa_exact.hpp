@@ -576,6 +576,12 @@ public:
     // end row, a bubble with paths of different lengths, far-away reached offsets, ends-free spans — takes the generic code:
     // same results, more round trips.  The logic below is reached.rs:38-255 specialised to tmin == tmax.
     uint32_t n_fast = 0;      // states tested on this path (statistics)
+#if defined(POA_EXACT_DIAG)
+    uint32_t diag[8][3] = {};   // [why inspect_fast declined][state]
+#define EXD(r, st) (diag[r][st]++)
+#else
+#define EXD(r, st) ((void)0)
+#endif
     // the test of one bubble whose exit lies a fixed distance ahead (tmin == tmax == t): reached bits around t and the
     // Match scores next to t, loaded together
     struct Probe {
@@ -670,15 +676,15 @@ public:
         F.kind = 0;
         const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
         // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341 — so a branching row is fine for it)
-        if (C.ends_free || (s1 - s0 != 1 && (st != EX_ST_I || s1 == s0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) return 3;
+        if (C.ends_free || (s1 - s0 != 1 && (st != EX_ST_I || s1 == s0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) { EXD(s1 - s0 != 1 ? 1 : 2, st); return 3; }
         const uint32_t c = gld(&G.succ[s0]);
         Probe P;
-        if (!probe_setup(v, j, P, true)) return 3;
+        if (!probe_setup(v, j, P, true)) { EXD(3, st); return 3; }
         uint32_t kind = 1;
         if (st == EX_ST_M) {
             // a Match state goes through the greedy extension: a single successor that is not the end, query not exhausted
-            if (c == G.end_row || j >= L) return 3;
-            if (j == 0 && L != 0 && is_symbol_equal(v, seq[0])) return 3;  // the offset-0 special case, dfa.rs:146-167
+            if (c == G.end_row || j >= L) { EXD(4, st); return 3; }
+            if (j == 0 && L != 0 && is_symbol_equal(v, seq[0])) { EXD(4, st); return 3; }  // the offset-0 special case, dfa.rs:146-167
             if (gld(&G.sym[c]) == seq[j]) kind = 2;
         }
         // ---- every load of the step, before any use ----
@@ -691,7 +697,8 @@ public:
         n_fast += 1;
         if (g > own) return 1;                      // stale (astar.rs:146)
         const uint32_t r = probe_decide(P, g, st);
-        if (r == 3) return 3;
+        if (r == 3) { EXD(5, st); return 3; }
+        EXD(r == 0 ? (kind == 2 ? 7 : 6) : 0, st);
         F.kind = kind; F.c = c; F.t0 = t0; F.t1 = t1; F.t2 = t2;
         return r;
     }

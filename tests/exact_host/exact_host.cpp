@@ -65,6 +65,12 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     ExactSearch S(G, W, seq, len, EC);
     ExactResult R = g_batch ? S.run_buckets(g_batch) : S.run();
     if (getenv("EXH_VERBOSE")) fprintf(stderr, "chunks used %u of %u, status %u, fast-path tests %u, queued %u\n", S.bq_chunk_top, W.bq_chunk_cap, R.status, S.n_fast, R.num_queued);
+#if defined(POA_EXACT_DIAG)
+    if (getenv("EXH_VERBOSE")) {
+        const char* why[8] = {"stale/pruned on the fast path", "several successors", "end row / misc", "bubble shape", "Match special", "probe undecided", "fast expand", "fast greedy walk"};
+        for (int r = 0; r < 8; ++r) fprintf(stderr, "  %-32s M %8u  D %8u  I %8u\n", why[r], S.diag[r][0], S.diag[r][1], S.diag[r][2]);
+    }
+#endif
     out[0] = R.score; out[1] = R.num_queued; out[2] = R.num_visited; out[3] = R.num_pruned;
     if (span) { out[4] = g.rows[R.end_row].node; out[5] = R.end_off; }
     if (pm) {
