@@ -492,11 +492,52 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
     }
     bool reached_start = done;  // nothing to truncate in the special cases
     uint32_t d_run = 0;         // deletion steps taken in the current run (wave-uniform)
+    uint32_t i_run = 0;         // insertion cycles taken in the current run (wave-uniform)
     while (!done) {
         // speculation: in Match state lane i assumes i (mis)matches into the previous row came before it, in Deletion
         // state i deletion-extensions into the previous row (long deletion runs: a read against a much longer graph)
         uint32_t depth = 1;
         const uint32_t max_depth = P.spec_depth < (uint32_t)GW ? P.spec_depth : (uint32_t)GW;
+        // Insertion runs (a read's unaligned tail: tens of bases).  The reference's insertion step lands on the MATCH cell to
+        // its left (gap_affine.rs:649) and re-enters the Insertion state from there through the zero-cost gap close, so one
+        // inserted base is two steps of the walk: I(row, j) -> M(row, j-1) -> I(row, j-1).  Lane i evaluates that pair of
+        // steps at column j - i, assuming i such cycles came before it (the Insertion cell it starts from then holds the Match
+        // cell's score); the longest prefix of lanes whose cycle is exactly that — both steps found, no reference panic — is
+        // taken at once, with the ambiguity / start-quirk flags of both steps.  Anything else (run ends, gap opens, a panic)
+        // is left to the ordinary one-step code below, which makes the same decisions one at a time.
+        if (cst == 2 && crow != c.start_row && max_depth > 1 && cj > 1) {
+            uint32_t idepth = i_run < max_depth ? (i_run ? i_run : 1u) : max_depth;   // ramp up: most insertions are one base long
+            if (idepth < 2) idepth = 2;
+            if (cj < idepth) idepth = cj;
+            const bool iact = lane < idepth;
+            const uint32_t jj = cj - lane;
+            TbStep sI{0, 0, 0, false, 0, 0}, sM{0, 0, 0, false, 0, 0};
+            uint32_t ncI = 0, ncM = 0;
+            bool badI = false, pnI = false, badM = false, pnM = false;
+            if (iact) {
+                const uint32_t gcs_i = lane == 0 ? gcs : plM(c, crow, jj);
+                sI = tb_step<T, COMPACT>(c, crow, jj, 2, gcs_i, ncI, badI, pnI);
+                if (sI.found && !pnI && sI.st == 0) sM = tb_step<T, COMPACT>(c, sI.row, sI.j, 0, INF, ncM, badM, pnM);
+            }
+            const bool cyc = iact && sI.found && !pnI && sI.st == 0 && sI.row == crow && sI.j + 1 == jj &&
+                             sM.found && !pnM && sM.st == 2 && sM.row == crow && sM.j == sI.j;
+            const uint64_t cb = gballot(cyc);
+            const uint32_t ip = (cb == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~cb);   // accepted cycles, <= idepth
+            if (ip > 0) {
+                const uint64_t low = (ip >= 64) ? ~0ull : ((1ull << ip) - 1ull);
+                const bool ambI = iact && ((ncI != 1 || badI) || (ncM != 1 || badM));
+                const bool quirkI = iact && sI.j == 0 && (uint32_t)c.rows[crow].sym == (uint32_t)c.q[0];   // (crow is not the start row here)
+                if (gballot(ambI) & low) flags |= POA_FLAG_AMBIGUOUS;
+                if (gballot(quirkI) & low) flags |= POA_FLAG_START_QUIRK;
+                if (lane < ip) emit_at(cnt + lane, POA_NONE, jj - 1);
+                cnt += ip;
+                cj -= ip;
+                gcs = bc(sM.cs, ip - 1);   // the Insertion cell entered last has the Match cell's score
+                i_run += ip;
+                continue;
+            }
+        }
+        if (cst != 2) i_run = 0;
         if (cst == 0) {
             depth = max_depth;
             if (crow + 1 < depth) depth = crow + 1;
