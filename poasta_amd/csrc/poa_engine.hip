@@ -663,10 +663,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         b->ran = true;
         return POA_OK;
     }
-    uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round); measured best: 12 with 64-lane groups, 16 with 16
+    uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round) of the full-plane layouts; the compact one: see the launch below
     if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
-    // lanes per traced query: 16 (four walks per wave) once there are more queries than wave slots, else 64
-    int tb_group = 16;
+    int tb_group = 16;   // POA_TB_GROUP override (lanes per walk); default: chosen per chunk at the launch below
     if (const char* gv = getenv("POA_TB_GROUP")) { const int v = atoi(gv); if (v == 8 || v == 16 || v == 32 || v == 64) tb_group = v; }
     bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
     if (const char* fv = getenv("POA_FUSE_TB")) fuse_tb = atoi(fv) != 0;
@@ -783,18 +782,22 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         HIP_TRY(hipEventRecord(events[ev++], stream));
 
         if (!(fuse_tb && !relative && max_pitch <= 1024 && (!compact || packed))) {
-            // four walks per wave only when one walk per wave would exceed the chip's wave slots (256 CUs x 32)
-            const int tbg = (getenv("POA_TB_GROUP") || ch.count > 4096) ? tb_group : 64;   // measured: 4 096 walks 1.13 vs 1.17 ms, 8 192 walks 1.90 vs 1.41 ms (64 vs 16 lanes)
+            // Lanes per walk: as many as keep the launch within ~6 000 waves (what the chip holds at this kernel's occupancy
+            // with room to spare), and a speculation depth to match.  Measured on config 2 after the insertion-run speculation
+            // (ms per batch; 64 lanes x depth 32 / 32 x 32 / 16 x 16): 1 024 walks 0.44 / 0.57 / 0.74, 4 096 walks 0.68 / 0.77 /
+            // 0.84, 10 000 walks 1.22 / 0.97 / 1.05, 20 000 walks 2.22 / 1.79 / 1.35.
+            int tbg = ch.count <= 6144 ? 64 : (ch.count <= 12288 ? 32 : 16);
+            if (getenv("POA_TB_GROUP")) tbg = tb_group;
+            TbParams tpg = tp;
+            if (!getenv("POA_TB_DEPTH")) tpg.spec_depth = tbg == 16 ? 16u : (compact ? 32u : spec_depth);
             if (compact && tbg == 16) {
-                TbParams tp16 = tp;
-                if (!getenv("POA_TB_DEPTH")) tp16.spec_depth = 16;
-                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 16>), dim3((ch.count + 15) / 16), dim3(256), 0, stream, tp16);
+                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 16>), dim3((ch.count + 15) / 16), dim3(256), 0, stream, tpg);
             } else if (compact && tbg == 32) {
-                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 32>), dim3((ch.count + 7) / 8), dim3(256), 0, stream, tp);
+                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 32>), dim3((ch.count + 7) / 8), dim3(256), 0, stream, tpg);
             } else if (compact && tbg == 8) {
-                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 8>), dim3((ch.count + 31) / 32), dim3(256), 0, stream, tp);
+                hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 8>), dim3((ch.count + 31) / 32), dim3(256), 0, stream, tpg);
             }
-            else if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
+            else if (compact) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tpg);
             else if (narrow) hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             else hipLaunchKernelGGL((poa_traceback_kernel<uint32_t, false>), dim3((ch.count + 3) / 4), dim3(256), 0, stream, tp);
             HIP_TRY(hipGetLastError());

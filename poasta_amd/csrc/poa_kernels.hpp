@@ -567,7 +567,7 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
         // nothing after it is defined
         const uint64_t pnb = gballot(active && pn);
         const uint32_t first_pn = pnb ? (uint32_t)__builtin_ctzll(pnb) : 64u;
-        const bool dies = first_pn <= p;
+        const bool dies = pnb != 0 && first_pn <= p;   // (p can be 64: the sentinel must not count)
         if (dies) p = first_pn;
         const uint64_t low = (p >= 64) ? ~0ull : ((1ull << p) - 1ull);
         if (gballot(amb) & low) flags |= POA_FLAG_AMBIGUOUS;

@@ -340,3 +340,33 @@ def test_flag_encodings_of_the_one_strip_kernel_agree(engine, oracle):
     assert np.array_equal(runs[2].score, D["score"]) and np.array_equal(runs[2].flags, D["flags"])
     for i in range(40):
         assert runs[2].raw_alignment(i) == oracle.batch_alignment(D, i)
+
+
+def test_traceback_is_the_same_walk_at_every_speculation_width(engine):
+    """Lanes per walk and speculation depth only change how many steps a round of the traceback takes at once (diagonal runs,
+    deletion runs, insertion runs): pairs and flags must not move — including depth 64, where a whole wave is accepted."""
+    import os
+    g, (qseq, qoff) = W.config2(n_queries=600)        # reads that end in ~75 inserted bases
+    costs = _costs(engine)
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            rb = engine.ResidentBatch(g, qseq, qoff)
+            rb.run(costs)
+            r = rb.fetch()
+            rb.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        return r
+    ref = run({"POA_TB_GROUP": "16", "POA_TB_DEPTH": "1"})     # one step per round: the sequential rule
+    assert int((ref.pairs[:, 0] == 0xFFFFFFFF).sum()) > 20000   # the insertion runs are there
+    for grp, depth in ((64, 64), (64, 32), (32, 32), (16, 16), (8, 8), (64, 2)):
+        r = run({"POA_TB_GROUP": str(grp), "POA_TB_DEPTH": str(depth)})
+        assert np.array_equal(r.flags, ref.flags) and np.array_equal(r.pair_off, ref.pair_off) and np.array_equal(r.pairs, ref.pairs), (grp, depth)
+    r = run({})
+    assert np.array_equal(r.flags, ref.flags) and np.array_equal(r.pairs, ref.pairs)
