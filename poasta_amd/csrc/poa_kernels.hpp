@@ -536,6 +536,19 @@ __device__ __forceinline__ void traceback_wave(const TbParams& P, const uint32_t
                 i_run += ip;
                 continue;
             }
+            // no full cycle at lane 0 (the run ends here): its Insertion step is evaluated already — take it as the ordinary
+            // code below would (one round instead of two for the last base of every run)
+            if (bc((sI.found && !pnI) ? 1u : 0u, 0)) {
+                if (bc((ncI != 1 || badI) ? 1u : 0u, 0)) flags |= POA_FLAG_AMBIGUOUS;
+                if (lane == 0) emit_at(cnt, POA_NONE, cj - 1);
+                cnt += 1;
+                const uint32_t n_row = bc(sI.row, 0), n_j = bc(sI.j, 0), n_st = bc(sI.st, 0);
+                if (n_st == 0 && n_j == 0 && n_row != c.start_row && (uint32_t)c.rows[n_row].sym == (uint32_t)c.q[0]) flags |= POA_FLAG_START_QUIRK;
+                if (n_row == c.start_row) { reached_start = true; break; }
+                crow = n_row; cj = n_j; cst = n_st;
+                i_run = 0;
+                continue;
+            }
         }
         if (cst != 2) i_run = 0;
         if (cst == 0) {
