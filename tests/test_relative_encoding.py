@@ -143,6 +143,19 @@ def test_relative_hybrid_is_the_reference(engine, oracle):
         assert A["status"][i] == 0
         assert int(res.score[i]) == int(A["score"][i])
         assert res.raw_alignment(i) == oracle.batch_alignment(A, i)
+    # the same in workspace-limited chunks: the dense pass packs its compact planes into the u32-sized slots of the replay's plan
+    per_query_u32 = 3 * g.n * 256 * 4
+    rb = engine.ResidentBatch(g, qseq, qoff, workspace_bytes=int(2.2 * per_query_u32))
+    for mode in ("hybrid", None):
+        rb.run(_costs(engine, *costs), None, engine.make_config(mode) if mode else None)
+        r2 = rb.fetch()
+        assert r2.stats["n_chunks"] >= (3 if mode else 1)
+        assert "relative" in rb.layout()
+        if mode:
+            assert np.array_equal(r2.score, res.score) and np.array_equal(r2.pairs, res.pairs) and np.array_equal(r2.flags, res.flags)
+        else:
+            assert np.array_equal(r2.score, res.score)
+    rb.close()
 
 
 def test_bound_decides_the_layout(engine):
