@@ -516,15 +516,38 @@ public:
     // ---- depth-first greedy extension (dfa.rs:138-250) -----------------------------------------
     enum : uint32_t { EV_NONE = 0, EV_REF_GRAPH_END = 1, EV_QUERY_END = 2, EV_MISMATCH = 3 };
     struct Event { uint32_t kind, prow, poff, crow, coff; };
+    // The stack of the extension (dfa.rs:86-134).  Its top entry lives in registers (dfa_top), W.stack holds what is below
+    // it: the loop below works on the top only, and a read-after-write of a stack slot in memory costs a full round trip.
+    // A parent that has no successor left once a child is taken is not kept under that child (popping it later has no
+    // effect in the reference: SuccessorsExhausted, dfa.rs:246) — along chains the stack stays one entry deep.  The stack
+    // length is therefore not the reference's; the one place that reads it (the offset-0 special case, dfa.rs:146) also
+    // requires the bottom entry itself, which alone has offset 0.
     uint32_t sp = 0, dfa_visited = 0;
     uint32_t dfa_score = 0;
+    ExStackEntry dfa_top{0, 0, 0};
+    POA_HD void dfa_start(uint32_t row, uint32_t off) {
+        sp = 1;
+        dfa_top = ExStackEntry{row, off, gld(&G.succ_off[row])};
+    }
+    POA_HD void dfa_push(uint32_t row, uint32_t off, bool parent_exhausted) {
+        if (!parent_exhausted) {
+            if (sp >= W.stack_cap) { err = EX_POOL_FULL; return; }
+            W.stack[sp - 1] = dfa_top;
+            sp += 1;
+        }
+        dfa_top = ExStackEntry{row, off, gld(&G.succ_off[row])};
+    }
+    POA_HD void dfa_pop() {
+        sp -= 1;
+        if (sp != 0) dfa_top = W.stack[sp - 1];
+    }
 
     POA_HD Event dfa_extend() {
         if (sp == 1 && L != 0) {
-            const ExStackEntry init = W.stack[0];
+            const ExStackEntry init = dfa_top;
             if (init.offset == 0 && is_symbol_equal(init.row, seq[0])) {
                 if (update_if_lower(init.row, 1, EX_ST_M, dfa_score)) {
-                    W.stack[0] = ExStackEntry{init.row, 1, gld(&G.succ_off[init.row])};
+                    dfa_top = ExStackEntry{init.row, 1, gld(&G.succ_off[init.row])};
                     mark_reached(init.row, 1, EX_ST_M);
                     dfa_visited += 1;
                     if (1 == L) return Event{EV_REF_GRAPH_END, init.row, 0, init.row, 1};
@@ -532,7 +555,7 @@ public:
             }
         }
         while (sp != 0) {
-            ExStackEntry& parent = W.stack[sp - 1];
+            ExStackEntry& parent = dfa_top;
             const uint32_t cend = gld(&G.succ_off[parent.row + 1]);
             bool again = false;
             while (parent.it < cend) {
@@ -549,8 +572,8 @@ public:
                         if (err) return Event{EV_NONE, 0, 0, 0, 0};
                         mark_reached(child, coff, EX_ST_M);
                         dfa_visited += 1;
-                        if (sp >= W.stack_cap) { err = EX_POOL_FULL; return Event{EV_NONE, 0, 0, 0, 0}; }
-                        W.stack[sp++] = ExStackEntry{child, coff, gld(&G.succ_off[child])};
+                        dfa_push(child, coff, parent.it >= cend);
+                        if (err) return Event{EV_NONE, 0, 0, 0, 0};
                         again = true;
                         break;
                     }
@@ -559,7 +582,7 @@ public:
                 }
             }
             if (err) return Event{EV_NONE, 0, 0, 0, 0};
-            if (!again) sp -= 1;
+            if (!again) dfa_pop();
         }
         return Event{EV_NONE, 0, 0, 0, 0};
     }
@@ -755,8 +778,7 @@ public:
             dfa_visited += 1;
             if (!walk_on) {
                 // the tip is not a plain chain row: the generic extension goes on from it (its ancestors have nothing left)
-                sp = 0;
-                W.stack[sp++] = ExStackEntry{cc, nj, s0};
+                dfa_start(cc, nj);
                 if (dfa_events(g, R, end_score)) return true;
                 break;
             }
@@ -781,7 +803,7 @@ public:
         if (C.prune && prune(score, row, off, st)) return 2;
         return 0;
     }
-    // the events of the greedy extension that stands in W.stack[0..sp) (astar.rs:167-204); true: the search ends (R.end_* set)
+    // the events of the greedy extension that stands on the stack (dfa_top + W.stack) (astar.rs:167-204); true: the search ends (R.end_* set)
     POA_HD bool dfa_events(uint32_t score, ExactResult& R, uint32_t& end_score) {
         for (;;) {
             const Event ev = dfa_extend();
@@ -805,8 +827,8 @@ public:
         mark_reached(row, off, st);
         num_visited += 1;
         if (st == EX_ST_M) {
-            sp = 0; dfa_visited = 0; dfa_score = score;
-            W.stack[sp++] = ExStackEntry{row, off, gld(&G.succ_off[row])};
+            dfa_visited = 0; dfa_score = score;
+            dfa_start(row, off);
             if (dfa_events(score, R, end_score)) return true;
             num_visited += dfa_visited;  // skipped by `break 'main` (astar.rs:172,:205)
         } else {
