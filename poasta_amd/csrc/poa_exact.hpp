@@ -610,32 +610,40 @@ public:
     struct Probe {
         uint32_t on;          // 0: nothing to test (no such bubble, pruning off, t beyond the query)
         uint32_t ex, t, wi;
-        uint64_t w0, w1, w2, sum;
+        uint64_t w1, sum;     // the word of the reached set that holds t; the summary word (which words are non-empty)
         uint32_t ta, tb, tc;  // Match score of the exit row at t - 1, t, t + 1
     };
     // false: row v has not this shape (several bubbles ahead, or paths of different lengths through one)
     // (pop_level: the test at a pop is subject to enable_pruning, astar.rs:155; the one inside the greedy extension is not, dfa.rs:185)
-    POA_HD bool probe_setup(uint32_t v, uint32_t j, Probe& P, bool pop_level) const {
-        uint32_t ex = EX_NIL, dist = 0;
+    // Up to two such bubbles (the first node of an inserted branch lies in its own one-step bubble and in the branch's): P,
+    // then Q in the reference's order — a state is pruned as soon as one of its bubbles cannot be improved (gap_affine.rs:780-792).
+    POA_HD bool probe_setup(uint32_t v, uint32_t j, Probe& P, Probe& Q, bool pop_level) const {
+        uint32_t ex[2] = {EX_NIL, EX_NIL}, dist[2] = {0, 0}, n = 0;
         for (uint32_t k = gld(&G.nbm_off[v]), k1 = gld(&G.nbm_off[v + 1]); k < k1; ++k) {
             const FlatGraph::NodeBubble b = gld(&G.nbm[k]);
             if (b.exit_row == v) continue;                  // reached.rs:56-58
-            if (ex != EX_NIL || b.min_dist != b.max_dist) return false;
-            ex = b.exit_row; dist = b.min_dist;
+            if (n == 2 || b.min_dist != b.max_dist) return false;
+            ex[n] = b.exit_row; dist[n] = b.min_dist; n += 1;
         }
-        P.ex = ex; P.t = j + dist; P.wi = P.t >> 6;
-        P.on = ((C.prune || !pop_level) && ex != EX_NIL && P.t <= L) ? 1u : 0u;   // reached.rs:63-65: tmax > len -> can improve
-        return !(P.on && P.t + 1 >= W.pitch);                     // (the loads below read t + 1)
+        P.ex = ex[0]; P.t = j + dist[0]; P.wi = P.t >> 6;
+        P.on = ((C.prune || !pop_level) && ex[0] != EX_NIL && P.t <= L) ? 1u : 0u;   // reached.rs:63-65: tmax > len -> can improve
+        Q.ex = ex[1]; Q.t = j + dist[1]; Q.wi = Q.t >> 6;
+        Q.on = ((C.prune || !pop_level) && ex[1] != EX_NIL && Q.t <= L) ? 1u : 0u;
+        return !((P.on && P.t + 1 >= W.pitch) || (Q.on && Q.t + 1 >= W.pitch));   // (the loads below read t + 1)
+    }
+    // both tests: 0 can improve, 2 pruned, 3 undecided (the generic code decides)
+    POA_HD uint32_t probe_decide2(const Probe& P, const Probe& Q, uint32_t g, uint32_t st) {
+        const uint32_t r = probe_decide(P, g, st);
+        if (r != 0 || !Q.on) return r;
+        return probe_decide(Q, g, st);
     }
     POA_HD void probe_load(Probe& P) const {
-        P.w0 = P.w1 = P.w2 = P.sum = 0; P.ta = P.tb = P.tc = EX_INF;
+        P.w1 = P.sum = 0; P.ta = P.tb = P.tc = EX_INF;
         if (!P.on) return;
         const uint32_t x = gld(&G.exit_idx[P.ex]);
         const uint64_t* bits = W.reached + (uint64_t)x * W.wpn;
         P.sum = W.rsum[(uint64_t)x * W.swpn];
         P.w1 = bits[P.wi];
-        if (P.wi) P.w0 = bits[P.wi - 1];
-        if (P.wi + 1 < W.wpn) P.w2 = bits[P.wi + 1];
         if (P.t) P.ta = *cell(P.ex, P.t - 1, EX_ST_M);
         P.tb = *cell(P.ex, P.t, EX_ST_M);
         P.tc = *cell(P.ex, P.t + 1, EX_ST_M);
@@ -648,13 +656,12 @@ public:
         uint32_t prev = EX_NIL, nxt = EX_NIL;
         const bool at_t = (P.w1 >> (t & 63)) & 1;
         const uint64_t lo = (t & 63) ? (P.w1 & (~0ull >> (64 - (t & 63)))) : 0ull;
+        // (a neighbour outside t's word — t next to a word boundary, or a sparse set — is found through the summary: one more load)
         if (lo) prev = wi * 64 + 63 - (uint32_t)clz64(lo);
-        else if (wi && P.w0) prev = (wi - 1) * 64 + 63 - (uint32_t)clz64(P.w0);
-        else if (wi > 1 && (P.sum & (~0ull >> (64 - (wi - 1))))) prev = reached_before(ex, (wi - 1) * 64);   // far away: generic lookup
+        else if (wi && (P.sum & (~0ull >> (64 - wi)))) prev = reached_before(ex, wi * 64);
         const uint64_t hi = (t & 63) != 63 ? (P.w1 & (~0ull << ((t & 63) + 1))) : 0ull;
         if (hi) nxt = wi * 64 + (uint32_t)ctz64(hi);
-        else if (wi + 1 < W.wpn && P.w2) nxt = (wi + 1) * 64 + (uint32_t)ctz64(P.w2);
-        else if (wi + 2 < W.wpn && (P.sum >> (wi + 2))) nxt = reached_from(ex, (wi + 2) * 64);
+        else if (wi + 1 < W.wpn && (P.sum >> (wi + 1))) nxt = reached_from(ex, (wi + 1) * 64);
         // scores of the two neighbours: next to t they are loaded already; else both loads go out together
         const uint32_t lq = *cell(ex, prev != EX_NIL && prev < W.pitch ? prev : t, EX_ST_M);
         const uint32_t rq = *cell(ex, nxt != EX_NIL && nxt < W.pitch ? nxt : t, EX_ST_M);
@@ -701,8 +708,8 @@ public:
         // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341 — so a branching row is fine for it)
         if (C.ends_free || (s1 - s0 != 1 && (st != EX_ST_I || s1 == s0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) { EXD(s1 - s0 != 1 ? 1 : 2, st); return 3; }
         const uint32_t c = gld(&G.succ[s0]);
-        Probe P;
-        if (!probe_setup(v, j, P, true)) { EXD(3, st); return 3; }
+        Probe P, Q;
+        if (!probe_setup(v, j, P, Q, true)) { EXD(3, st); return 3; }
         uint32_t kind = 1;
         if (st == EX_ST_M) {
             // a Match state goes through the greedy extension: a single successor that is not the end, query not exhausted
@@ -717,9 +724,10 @@ public:
         else if (st == EX_ST_I) { t0 = *cell(v, j, EX_ST_M); t1 = j < L ? *cell(v, j + 1, EX_ST_I) : EX_INF; }
         else { t0 = *cell(v, j, EX_ST_M); t1 = *cell(c, j, EX_ST_D); }
         probe_load(P);
+        probe_load(Q);
         n_fast += 1;
         if (g > own) return 1;                      // stale (astar.rs:146)
-        const uint32_t r = probe_decide(P, g, st);
+        const uint32_t r = probe_decide2(P, Q, g, st);
         if (r == 3) { EXD(5, st); return 3; }
         EXD(r == 0 ? (kind == 2 ? 7 : 6) : 0, st);
         F.kind = kind; F.c = c; F.t0 = t0; F.t1 = t1; F.t2 = t2;
@@ -764,13 +772,13 @@ public:
             // what the tip needs next: its own successor, its bubble test, and what a mismatch there relaxes
             const uint32_t s0 = gld(&G.succ_off[cc]), s1 = gld(&G.succ_off[cc + 1]);
             const uint32_t nc = s1 - s0 == 1 ? gld(&G.succ[s0]) : EX_NIL;
-            Probe P;
-            const bool shaped = probe_setup(cc, nj, P, false);
+            Probe P, Q;
+            const bool shaped = probe_setup(cc, nj, P, Q, false);
             const bool walk_on = shaped && nc != EX_NIL && nc != G.end_row && nj < L && nj + 2 < W.pitch;
             uint32_t n0 = EX_INF, n1 = EX_INF, n2 = EX_INF;
-            if (shaped) probe_load(P);
+            if (shaped) { probe_load(P); probe_load(Q); }
             if (walk_on) { n0 = *cell(nc, nj + 1, EX_ST_M); n1 = *cell(cc, nj + 1, EX_ST_I); n2 = *cell(nc, nj, EX_ST_D); }
-            uint32_t pr = shaped ? probe_decide(P, g, EX_ST_M) : 3u;
+            uint32_t pr = shaped ? probe_decide2(P, Q, g, EX_ST_M) : 3u;
             if (pr == 3) pr = prune(g, cc, nj, EX_ST_M) ? 2u : 0u;
             if (err) break;
             if (pr == 2) { num_pruned_dfa += 1; break; }   // scored, not extended (dfa.rs:185-188)
