@@ -20,6 +20,7 @@
 #include "poa_graph.hpp"
 #include "poa_exact_kernel.hpp"
 #include "poa_wsearch.hpp"
+#include "poa_psearch.hpp"
 #include "poa_kernels.hpp"
 #include "poa_forward_packed.hpp"
 #include "poa_forward_px.hpp"
@@ -215,6 +216,7 @@ struct poa_batch {
     DevBuf<uint32_t> d_pipeline_error;   // FwdParams::pipeline_error
     DevBuf<unsigned long long> d_ex_prof;
     DevBuf<uint32_t> d_ex_counters;    // wave search: num_queued, num_visited, num_pruned, steps per query
+    DevBuf<uint32_t> d_ex_logs;        // parallel-step search (poa_psearch.hpp): the lanes' logs, per resident wave
     bool exact_ready = false;
     uint32_t last_mode = 0;
 
@@ -849,7 +851,68 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             const uint32_t graph_lds = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
             const char* impl = getenv("POA_EXACT_IMPL");
             const bool wave_search = !(impl && !strcmp(impl, "lane")) && win <= b->ex_n_prio;
-            if (wave_search) {
+            const bool par_search = wave_search && !(impl && !strcmp(impl, "wave"));
+            if (par_search) {
+                // the top entries of a stack expanded at once, one per lane (poa_psearch.hpp)
+                PSearchParams pp;
+                pp.E = ep;
+                pp.chunks = reinterpret_cast<ExU4*>(b->d_ex_pool.p);
+                pp.chunk_cap = b->ex_pool_cap / BQ_CHUNK;
+                if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < pp.chunk_cap) pp.chunk_cap = (uint32_t)v; }
+                pp.win = win;
+                pp.counters = b->d_ex_counters.p;
+                pp.max_lanes = 63;
+                if (const char* lv = getenv("POA_PS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) pp.max_lanes = (uint32_t)v; }
+                pp.rmax = 8;
+                if (const char* lv = getenv("POA_PS_ROUNDS")) { const int v = atoi(lv); if (v >= 1 && v <= 64) pp.rmax = (uint32_t)v; }
+                pp.prof = nullptr;
+                if (getenv("POA_WS_PROF")) {
+                    HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
+                    pp.prof = b->d_ex_prof.p;
+                }
+                // LDS of a block: the staged graph (shared by its waves) + per wave the descriptor ring and the read sets / conflict
+                // table of the step.  As many waves per block as fit 160 KB, at most 8 (two per SIMD: the step keeps a lane's logs
+                // and read sets in ~200 registers).
+                const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 160u * 1024u);
+                const uint64_t ring_b = ((uint64_t)3 * win * 4 + 15) & ~15ull;
+                bool ring_lds = ring_b + ps_lds_bytes() <= lds_budget && !getenv("POA_WS_RING_GLOBAL");
+                uint64_t per_wave = (ring_lds ? ring_b : 0) + ps_lds_bytes();
+                bool stage = graph_lds + per_wave <= lds_budget;
+                if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
+                if (!stage && ring_lds && per_wave > lds_budget) { ring_lds = false; per_wave = ps_lds_bytes(); }
+                uint32_t wpb = (uint32_t)std::min<uint64_t>(8, (lds_budget - (stage ? graph_lds : 0)) / per_wave);
+                if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && (uint32_t)v <= wpb) wpb = (uint32_t)v; }
+                if (wpb < 1) return fail(POA_ERR_UNSUPPORTED, "exact replay: the step's read sets do not fit the LDS");
+                pp.graph_lds = stage ? graph_lds : 0;
+                pp.waves_per_block = wpb;
+                pp.ring_global = ring_lds ? nullptr : b->d_ex_head.p;   // [slots * 3 * ex_n_prio] holds slots * 3 * win
+                const uint32_t lds_bytes = pp.graph_lds + (uint32_t)(wpb * per_wave);
+                const void* kfn = reinterpret_cast<const void*>(poa_psearch_kernel);
+                if (lds_bytes > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                uint32_t n_blocks = (ch.count + wpb - 1) / wpb;
+                pp.work_counter = nullptr; pp.order = nullptr;
+                int per_cu = 1, cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)(64 * wpb), lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+                const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
+                if (n_blocks > resident && !getenv("POA_WS_STATIC")) {
+                    // persistent waves, longest expected search first (see the wave search below)
+                    std::vector<uint32_t> sc(ch.count), ord(ch.count);
+                    HIP_TRY(hipMemcpyAsync(sc.data(), b->d_score.p + ch.first, (size_t)ch.count * 4, hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    for (uint32_t i = 0; i < ch.count; ++i) ord[i] = i;
+                    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c2) { return sc[a] > sc[c2]; });
+                    HIP_TRY(b->d_ex_order.alloc(ch.count + 1));
+                    HIP_TRY(hipMemcpyAsync(b->d_ex_order.p + 1, ord.data(), (size_t)ch.count * 4, hipMemcpyHostToDevice, stream));
+                    HIP_TRY(hipMemsetAsync(b->d_ex_order.p, 0, 4, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));   // `ord` is a host temporary
+                    pp.work_counter = b->d_ex_order.p; pp.order = b->d_ex_order.p + 1;
+                    n_blocks = resident;
+                }
+                HIP_TRY(b->d_ex_logs.alloc((size_t)n_blocks * wpb * ps_scratch_words()));
+                pp.scratch = b->d_ex_logs.p;
+                hipLaunchKernelGGL(poa_psearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, pp);
+            } else if (wave_search) {
                 WSearchParams wp;
                 wp.E = ep;
                 wp.chunks = reinterpret_cast<ExU4*>(b->d_ex_pool.p);

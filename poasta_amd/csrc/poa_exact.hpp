@@ -27,6 +27,12 @@
 #define POA_HD
 #endif
 
+// analysis hooks (scripts/trace): what a pop reads and writes; no-ops in the product
+#if !defined(EX_TRACE_CELL)
+#define EX_TRACE_CELL(row, off, st, wr) ((void)0)
+#define EX_TRACE_REACH(row, lo, hi, wr) ((void)0)
+#endif
+
 namespace poa_amd {
 
 enum : uint32_t { EX_ST_M = 0, EX_ST_D = 1, EX_ST_I = 2 };
@@ -99,11 +105,47 @@ struct ExactCosts {
     uint32_t gfe_kind, gfe_val;   // graph_free_end
 };
 
+// ---- speculative ("log") mode of the search object: the step of the wave kernel poa_psearch.hpp ----------------------------
+// The top entries of the current stack are expanded by different lanes AT ONCE.  Each lane runs the ordinary code of this
+// file on its entry — and on the entries that expansion pushes in front of the next entry of the stack (same bucket, state
+// of equal or higher pop priority: they would be popped before it) — but reads the table as it was when the step began,
+// through an overlay of its own writes, and writes nothing: cell writes, reached marks and queue pushes go to a per-lane
+// log.  Afterwards the step finds the first lane that read something an earlier lane of the step logged a write to
+// (cell by cell, mark by mark), commits the logs of the lanes before it in lane order — exactly the writes and pushes the
+// reference's sequential loop makes — and leaves the rest of the stack for the next step.
+constexpr uint32_t SP_KW = 12;   // cell writes a lane may log per step
+constexpr uint32_t SP_KM = 8;    // reached marks
+constexpr uint32_t SP_KP = 12;   // queue pushes (those that do not come back within the lane's own group)
+constexpr uint32_t SP_KPD = 4;   // pending entries of the lane's own group
+constexpr uint32_t SP_KRC = 32;  // cells whose value a lane's decisions depended on
+constexpr uint32_t SP_KRM = 6;   // ranges of a reached set they depended on
+constexpr uint32_t SP_KDS = 4;   // depth of the greedy extension's stack (parents with successors left)
+enum : uint32_t {
+    SPF_COMPLEX = 1,    // the lane met something the log mode does not do (log / box overflow, an error, a greedy extension
+                        // that needs its stack): it is cut off and its entry takes the sequential code
+    SPF_FOUND = 2,      // the search ends in this lane
+    SPF_LEFTOVER = 4,   // entries of the lane's group are still pending: they go to the queue and the step ends behind this lane
+};
+struct SpecLane {
+    uint32_t n_w = 0, n_m = 0, n_p = 0, n_pd = 0, flags = 0;
+    uint32_t dq = 0, dv = 0, dp = 0, n_ent = 0;   // num_queued / num_visited / num_pruned of this lane's step; entries it processed
+    uint32_t cur_f = 0, root_st = 0;              // the stack the step pops from
+    // logs: element k of this lane at base[k * stride]
+    uint32_t* w_idx = nullptr; uint32_t* w_val = nullptr; uint32_t* m_x = nullptr; uint32_t* m_off = nullptr;
+    ExU4* p = nullptr;                            // {score, row, offset, priority << 2 | state}
+    ExStackEntry* dstack = nullptr;               // the lane's own stack of the greedy extension
+    uint32_t stride = 1;
+    uint32_t pd_key[SP_KPD] = {}, pd_score[SP_KPD] = {}, pd_row[SP_KPD] = {}, pd_off[SP_KPD] = {};   // in push order
+    // what the lane read: cells (index into the table) and ranges [lo, hi] of the reached set of exit x — element k at base[k * stride]
+    uint32_t n_rc = 0, n_rm = 0;
+    uint32_t* rc = nullptr; uint32_t* rm_x = nullptr; uint32_t* rm_lo = nullptr; uint32_t* rm_hi = nullptr;
+};
+
 // Address-space tags of the two tables a kernel may stage in LDS (the graph arrays; the queue's descriptor ring).  A pointer
 // that may be global or LDS compiles to FLAT loads, which wait for every outstanding vector-memory AND LDS operation
 // (they count on both counters): one such load in the middle of a batch of table reads serialises the batch.  With the
 // tag the access is a ds_read / ds_write and overlaps with the global loads in flight.
-enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2 };
+enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4 };   // (4: the read sets of the log mode, SpecLane::rc / rm_*)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T> __device__ inline __attribute__((always_inline)) T ex_lds_load(const T* p) {
     return *(const __attribute__((address_space(3))) T*)p;
@@ -134,6 +176,18 @@ public:
 #endif
         *p = v;
     }
+    POA_HD uint32_t sld(const uint32_t* p) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((AS & EX_AS_READSET_LDS) != 0) return ex_lds_load(p);
+#endif
+        return *p;
+    }
+    POA_HD void sst(uint32_t* p, uint32_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((AS & EX_AS_READSET_LDS) != 0) { ex_lds_store(p, v); return; }
+#endif
+        *p = v;
+    }
     const ExactGraph& G;
     ExactWork& W;
     const uint8_t* seq;
@@ -146,6 +200,73 @@ public:
 
     POA_HD ExactSearchT(const ExactGraph& g, ExactWork& w, const uint8_t* s, uint32_t len, ExactCosts c)
         : G(g), W(w), seq(s), L(len), C(c) {}
+
+    // ---- log mode (see SpecLane) ---------------------------------------------------------------
+    bool spec = false;
+    SpecLane sl;
+#if defined(POA_EXACT_DIAG)
+    uint32_t why_complex[12] = {};
+    void sp_flag(uint32_t f, uint32_t why = 0) { sl.flags |= f; why_complex[why] += 1; }
+#else
+    POA_HD void sp_flag(uint32_t f, uint32_t = 0) { sl.flags |= f; }
+#endif
+    // a cell / a range of a reached set whose content the lane's decisions depend on
+    POA_HD void note_cell(uint32_t ix) {
+        if (sl.n_rc >= SP_KRC) { sp_flag(SPF_COMPLEX, 1); return; }
+        sst(&sl.rc[sl.n_rc * sl.stride], ix);
+        sl.n_rc += 1;
+    }
+    POA_HD void note_marks(uint32_t x, uint32_t lo, uint32_t hi) {
+        // (one range per exit: the hull of what was looked at)
+        for (uint32_t k = 0; k < sl.n_rm; ++k)
+            if (sld(&sl.rm_x[k * sl.stride]) == x) {
+                if (lo < sld(&sl.rm_lo[k * sl.stride])) sst(&sl.rm_lo[k * sl.stride], lo);
+                if (hi > sld(&sl.rm_hi[k * sl.stride])) sst(&sl.rm_hi[k * sl.stride], hi);
+                return;
+            }
+        if (sl.n_rm >= SP_KRM) { sp_flag(SPF_COMPLEX, 2); return; }
+        sst(&sl.rm_x[sl.n_rm * sl.stride], x); sst(&sl.rm_lo[sl.n_rm * sl.stride], lo); sst(&sl.rm_hi[sl.n_rm * sl.stride], hi);
+        sl.n_rm += 1;
+    }
+    // the lane's own logged value of cell `ix`, else v
+    POA_HD uint32_t ovl(uint32_t ix, uint32_t v) const {
+        for (uint32_t k = 0; k < sl.n_w; ++k) if (sl.w_idx[k * sl.stride] == ix) v = sl.w_val[k * sl.stride];
+        return v;
+    }
+    POA_HD uint32_t cix(uint32_t row, uint32_t off, uint32_t st) const { return ex_cell_index32(row, off, st, W.n_rows, W.pitch); }
+    // visited score of a cell inside the table
+    POA_HD uint32_t ld(uint32_t row, uint32_t off, uint32_t st) {
+        const uint32_t ix = cix(row, off, st);
+        uint32_t v = W.T[ix];
+        if (spec) { note_cell(ix); if (sl.n_w) v = ovl(ix, v); }
+        return v;
+    }
+    POA_HD void wr(uint32_t row, uint32_t off, uint32_t st, uint32_t val) {
+        const uint32_t ix = cix(row, off, st);
+        EX_TRACE_CELL(row, off, st, 1);
+        if (!spec) { W.T[ix] = val; return; }
+        // (append only — a later entry for the same cell wins, in the overlay and at the commit — so that the log can be cut back)
+        if (sl.n_w >= SP_KW) { sp_flag(SPF_COMPLEX, 3); return; }
+        sl.w_idx[sl.n_w * sl.stride] = ix; sl.w_val[sl.n_w * sl.stride] = val;
+        sl.n_w += 1;
+    }
+    // words of the reached sets, with the lane's own logged marks
+    POA_HD uint64_t rword(uint32_t x, uint32_t wi) const {
+        uint64_t w = W.reached[(uint64_t)x * W.wpn + wi];
+        if (spec) for (uint32_t k = 0; k < sl.n_m; ++k) {
+            const uint32_t o = sl.m_off[k * sl.stride];
+            if (sl.m_x[k * sl.stride] == x && (o >> 6) == wi) w |= 1ull << (o & 63);
+        }
+        return w;
+    }
+    POA_HD uint64_t rsw(uint32_t x, uint32_t si) const {
+        uint64_t w = W.rsum[(uint64_t)x * W.swpn + si];
+        if (spec) for (uint32_t k = 0; k < sl.n_m; ++k) {
+            const uint32_t o = sl.m_off[k * sl.stride];
+            if (sl.m_x[k * sl.stride] == x && (o >> 12) == si) w |= 1ull << ((o >> 6) & 63);
+        }
+        return w;
+    }
 
     // ---- Score arithmetic (scoring/mod.rs:93-152) -------------------------------------------
     // (32-bit throughout: the engine refuses graphs / queries whose priorities could reach 2^26, so no sum here can wrap)
@@ -172,21 +293,17 @@ public:
     // not allowed to stop at the query end opens an insertion at offset len + 1 (expand_ref_graph_end has no bound,
     // gap_affine.rs:346-368).  The flat planes have `pitch` columns: beyond them a cell reads as unvisited and a write
     // is a workspace overflow (the query keeps its flag, nothing is written out of bounds).
-    POA_HD uint32_t get_score(uint32_t row, uint32_t off, uint32_t st) const { return off < W.pitch ? *cell(row, off, st) : EX_INF; }
+    POA_HD uint32_t get_score(uint32_t row, uint32_t off, uint32_t st) { EX_TRACE_CELL(row, off, st, 0); return off < W.pitch ? ld(row, off, st) : EX_INF; }
     POA_HD bool update_if_lower(uint32_t row, uint32_t off, uint32_t st, uint32_t s) {
         if (off >= W.pitch) { err = EX_POOL_FULL; return false; }
-        uint32_t* p = cell(row, off, st);
-        if (s < *p) { *p = s; return true; }
+        EX_TRACE_CELL(row, off, st, 0);
+        if (s < ld(row, off, st)) { wr(row, off, st, s); return true; }
         return false;
     }
 
     // ---- reached sets: BTreeSet<offset> per exit node as a two-level bitset (gap_affine.rs:711,:767-773) ---
-    POA_HD void mark_reached(uint32_t row, uint32_t off, uint32_t st) {
-        if (st != EX_ST_M) return;
-        const uint32_t x = gld(&G.exit_idx[row]);
-        if (x == EX_NIL) return;
+    POA_HD void mark_word(uint32_t x, uint32_t off) {   // the write itself (direct mode; commit of a logged mark)
         const uint32_t wi = off >> 6;
-        if (wi >= W.wpn) { err = EX_POOL_FULL; return; }
         uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
         uint64_t* sm = W.rsum + (uint64_t)x * W.swpn + (wi >> 6);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -198,56 +315,78 @@ public:
         *sm |= 1ull << (wi & 63);
 #endif
     }
-    POA_HD bool reached_any(uint32_t row) const {  // !reached_offsets.is_empty()
-        const uint64_t* s = W.rsum + (uint64_t)gld(&G.exit_idx[row]) * W.swpn;
-        for (uint32_t i = 0; i < W.swpn; ++i) if (s[i]) return true;
+    POA_HD void mark_reached(uint32_t row, uint32_t off, uint32_t st) {
+        if (st != EX_ST_M) return;
+        const uint32_t x = gld(&G.exit_idx[row]);
+        if (x == EX_NIL) return;
+        if ((off >> 6) >= W.wpn) { err = EX_POOL_FULL; return; }
+        EX_TRACE_REACH(row, off, off, 1);
+        if (!spec) { mark_word(x, off); return; }
+        for (uint32_t k = 0; k < sl.n_m; ++k) if (sl.m_x[k * sl.stride] == x && sl.m_off[k * sl.stride] == off) return;
+        if (sl.n_m >= SP_KM) { sp_flag(SPF_COMPLEX, 4); return; }
+        sl.m_x[sl.n_m * sl.stride] = x; sl.m_off[sl.n_m * sl.stride] = off;
+        sl.n_m += 1;
+    }
+    POA_HD bool reached_any(uint32_t row) {  // !reached_offsets.is_empty()
+        const uint32_t x = gld(&G.exit_idx[row]);
+        for (uint32_t i = 0; i < W.swpn; ++i) if (rsw(x, i)) return true;
+        EX_TRACE_REACH(row, 0, 0xFFFFFFFFu, 0);
+        if (spec) note_marks(x, 0, 0xFFFFFFFFu);   // (any mark on this row would change the answer)
         return false;
     }
     // largest reached offset < t, or EX_NIL  (row must be an exit row)
-    POA_HD uint32_t reached_before(uint32_t row, uint32_t t) const {
+    POA_HD uint32_t reached_before(uint32_t row, uint32_t t) {
+        const uint32_t r = reached_before_(row, t);
+        EX_TRACE_REACH(row, r == EX_NIL ? 0u : r, t ? t - 1 : 0u, 0);
+        if (spec && t) note_marks(gld(&G.exit_idx[row]), r == EX_NIL ? 0u : r, t - 1);
+        return r;
+    }
+    POA_HD uint32_t reached_before_(uint32_t row, uint32_t t) const {
         if (t == 0) return EX_NIL;
         const uint32_t x = gld(&G.exit_idx[row]);
-        const uint64_t* b = W.reached + (uint64_t)x * W.wpn;
-        const uint64_t* s = W.rsum + (uint64_t)x * W.swpn;
         uint32_t last = t - 1;
         if ((last >> 6) >= W.wpn) last = W.wpn * 64 - 1;
         const uint32_t wi = last >> 6;
-        const uint64_t w = b[wi] & (~0ull >> (63 - (last & 63)));
+        const uint64_t w = rword(x, wi) & (~0ull >> (63 - (last & 63)));
         if (w) return wi * 64 + 63 - (uint32_t)clz64(w);
         if (wi == 0) return EX_NIL;
         // non-empty words below wi, through the summary
         const uint32_t lw = wi - 1;
         int32_t si = (int32_t)(lw >> 6);
-        uint64_t sw = s[si] & (~0ull >> (63 - (lw & 63)));
+        uint64_t sw = rsw(x, (uint32_t)si) & (~0ull >> (63 - (lw & 63)));
         for (;;) {
             if (sw) {
                 const uint32_t fw = (uint32_t)si * 64 + 63 - (uint32_t)clz64(sw);
-                return fw * 64 + 63 - (uint32_t)clz64(b[fw]);
+                return fw * 64 + 63 - (uint32_t)clz64(rword(x, fw));
             }
             if (--si < 0) return EX_NIL;
-            sw = s[si];
+            sw = rsw(x, (uint32_t)si);
         }
     }
     // smallest reached offset >= t, or EX_NIL  (row must be an exit row)
-    POA_HD uint32_t reached_from(uint32_t row, uint32_t t) const {
+    POA_HD uint32_t reached_from(uint32_t row, uint32_t t) {
+        const uint32_t r = reached_from_(row, t);
+        EX_TRACE_REACH(row, t, r, 0);
+        if (spec) note_marks(gld(&G.exit_idx[row]), t, r);   // (EX_NIL: everything from t on)
+        return r;
+    }
+    POA_HD uint32_t reached_from_(uint32_t row, uint32_t t) const {
         const uint32_t wi = t >> 6;
         if (wi >= W.wpn) return EX_NIL;
         const uint32_t x = gld(&G.exit_idx[row]);
-        const uint64_t* b = W.reached + (uint64_t)x * W.wpn;
-        const uint64_t* s = W.rsum + (uint64_t)x * W.swpn;
-        const uint64_t w = b[wi] & (~0ull << (t & 63));
+        const uint64_t w = rword(x, wi) & (~0ull << (t & 63));
         if (w) return wi * 64 + (uint32_t)ctz64(w);
         const uint32_t nw = wi + 1;
         if (nw >= W.wpn) return EX_NIL;
         uint32_t si = nw >> 6;
-        uint64_t sw = s[si] & (~0ull << (nw & 63));
+        uint64_t sw = rsw(x, si) & (~0ull << (nw & 63));
         for (;;) {
             if (sw) {
                 const uint32_t fw = si * 64 + (uint32_t)ctz64(sw);
-                return fw * 64 + (uint32_t)ctz64(b[fw]);
+                return fw * 64 + (uint32_t)ctz64(rword(x, fw));
             }
             if (++si >= W.swpn) return EX_NIL;
-            sw = s[si];
+            sw = rsw(x, si);
         }
     }
     static POA_HD int clz64(uint64_t v) {
@@ -384,12 +523,11 @@ public:
         if (top == EX_NIL || n == BQ_CHUNK - 1) {
             const uint32_t c = bq_alloc();
             if (c == EX_NIL) return;
-            W.bq_chunks[(uint64_t)BQ_CHUNK * c] = ExU4{top, 0, 0, 0};
+            if (bq_wr) W.bq_chunks[(uint64_t)BQ_CHUNK * c] = ExU4{top, 0, 0, 0};
             top = c; n = 0;
         }
         n += 1;
-        W.bq_chunks[(uint64_t)BQ_CHUNK * top + n] = ExU4{score, row, off, 0};
-        rst(d, top << 6 | n);
+        if (bq_wr) { W.bq_chunks[(uint64_t)BQ_CHUNK * top + n] = ExU4{score, row, off, 0}; rst(d, top << 6 | n); }
         bq_live += 1;
     }
     // the stack the next pop comes from: lowest live priority, Match before Deletion before Insertion
@@ -405,6 +543,7 @@ public:
             if (d0 != BQ_EMPTY) { bq_release(d0 >> 6); if (bq_wr) rst(b, BQ_EMPTY); }
             if (d1 != BQ_EMPTY) { bq_release(d1 >> 6); if (bq_wr) rst(b + 1, BQ_EMPTY); }
             if (d2 != BQ_EMPTY) { bq_release(d2 >> 6); if (bq_wr) rst(b + 2, BQ_EMPTY); }
+            if (layer_min >= bq_hi) return false;   // (cannot happen while bq_live counts right: never walk off the ring)
             layer_min += 1;
         }
     }
@@ -419,6 +558,7 @@ public:
     POA_HD void queue_state(uint32_t row, uint32_t off, uint32_t st, uint32_t new_score) {
         const uint32_t pr64 = new_score + h(row, off, st);
         num_queued += 1;
+        if (spec) { spec_queue(pr64, st, new_score, row, off); return; }
         if (W.bq_desc) { bq_push(pr64, st, new_score, row, off); return; }
         if (pr64 >= W.n_prio || pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; }
         const uint32_t prio = pr64;
@@ -429,6 +569,39 @@ public:
         uint32_t* hd = &W.head[3 * (uint64_t)prio + st];
         W.pool[e] = ExQEntry{new_score, row, off, *hd};
         *hd = e;
+    }
+    // log mode: an entry that would be popped before the next entry of the stack the step pops from stays with the lane
+    // (lower bucket; same bucket and a state of equal or higher pop priority: M before D before I, gap_affine.rs:954-966);
+    // everything else is logged and pushed when the step commits
+    POA_HD void spec_queue(uint32_t prio, uint32_t st, uint32_t score, uint32_t row, uint32_t off) {
+        if (prio >= (1u << 26)) { sp_flag(SPF_COMPLEX, 9); return; }
+        const uint32_t key = prio << 2 | st;
+        if (prio < sl.cur_f || (prio == sl.cur_f && st <= sl.root_st)) {
+            if (sl.n_pd >= SP_KPD) { sp_flag(SPF_COMPLEX, 6); return; }
+#pragma unroll
+            for (uint32_t k = 0; k < SP_KPD; ++k) if (k == sl.n_pd) { sl.pd_key[k] = key; sl.pd_score[k] = score; sl.pd_row[k] = row; sl.pd_off[k] = off; }
+            sl.n_pd += 1;
+            return;
+        }
+        if (sl.n_p >= SP_KP) { sp_flag(SPF_COMPLEX, 5); return; }
+        sl.p[sl.n_p * sl.stride] = ExU4{score, row, off, key};
+        sl.n_p += 1;
+    }
+    // the pending entry the queue would pop next: lowest (priority, state), the most recently pushed among equals
+    POA_HD bool spec_pending_pop(uint32_t& score, uint32_t& row, uint32_t& off, uint32_t& st) {
+        if (sl.n_pd == 0) return false;
+        uint32_t best = 0, bkey = sl.pd_key[0];
+#pragma unroll
+        for (uint32_t k = 1; k < SP_KPD; ++k) if (k < sl.n_pd && sl.pd_key[k] <= bkey) { best = k; bkey = sl.pd_key[k]; }
+        uint32_t key = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < SP_KPD; ++k) if (k == best) { key = sl.pd_key[k]; score = sl.pd_score[k]; row = sl.pd_row[k]; off = sl.pd_off[k]; }
+        st = key & 3u;
+        // remove it, keeping the push order of the others
+#pragma unroll
+        for (uint32_t k = 0; k + 1 < SP_KPD; ++k) if (k >= best) { sl.pd_key[k] = sl.pd_key[k + 1]; sl.pd_score[k] = sl.pd_score[k + 1]; sl.pd_row[k] = sl.pd_row[k + 1]; sl.pd_off[k] = sl.pd_off[k + 1]; }
+        sl.n_pd -= 1;
+        return true;
     }
     POA_HD bool layer_empty(uint32_t prio) const {
         const uint32_t* hd = &W.head[3 * (uint64_t)prio];
@@ -492,11 +665,16 @@ public:
             return;
         }
         // three different cells: read them together, then relax in the reference's order (gap_affine.rs:393-430)
-        uint32_t* pm = cell(crow, coff, EX_ST_M); uint32_t* pi = cell(prow, poff + 1, EX_ST_I); uint32_t* pd = cell(crow, poff, EX_ST_D);
-        const uint32_t vm = *pm, vi = *pi, vd = *pd;
-        if (nm < vm) { *pm = nm; queue_state(crow, coff, EX_ST_M, nm); }
-        if (ng < vi) { *pi = ng; queue_state(prow, poff + 1, EX_ST_I, ng); }
-        if (ng < vd) { *pd = ng; queue_state(crow, poff, EX_ST_D, ng); }
+        EX_TRACE_CELL(crow, coff, EX_ST_M, 0); EX_TRACE_CELL(prow, poff + 1, EX_ST_I, 0); EX_TRACE_CELL(crow, poff, EX_ST_D, 0);
+        const uint32_t im = cix(crow, coff, EX_ST_M), ii = cix(prow, poff + 1, EX_ST_I), id = cix(crow, poff, EX_ST_D);
+        uint32_t vm = W.T[im], vi = W.T[ii], vd = W.T[id];
+        if (spec) {
+            note_cell(im); note_cell(ii); note_cell(id);
+            if (sl.n_w) { vm = ovl(im, vm); vi = ovl(ii, vi); vd = ovl(id, vd); }
+        }
+        if (nm < vm) { wr(crow, coff, EX_ST_M, nm); queue_state(crow, coff, EX_ST_M, nm); }
+        if (ng < vi) { wr(prow, poff + 1, EX_ST_I, ng); queue_state(prow, poff + 1, EX_ST_I, ng); }
+        if (ng < vd) { wr(crow, poff, EX_ST_D, ng); queue_state(crow, poff, EX_ST_D, ng); }
     }
     POA_HD void expand_all(uint32_t score, uint32_t row, uint32_t off, uint32_t st) {
         if (update_if_lower(row, off, EX_ST_M, score)) queue_state(row, off, EX_ST_M, score);
@@ -531,6 +709,13 @@ public:
     }
     POA_HD void dfa_push(uint32_t row, uint32_t off, bool parent_exhausted) {
         if (!parent_exhausted) {
+            if (spec) {   // (the stack in memory is the query's; a lane keeps a few entries of its own)
+                if (sp - 1 >= SP_KDS) { sp_flag(SPF_COMPLEX, 7); return; }
+                sl.dstack[(sp - 1) * sl.stride] = dfa_top;
+                sp += 1;
+                dfa_top = ExStackEntry{row, off, gld(&G.succ_off[row])};
+                return;
+            }
             if (sp >= W.stack_cap) { err = EX_POOL_FULL; return; }
             W.stack[sp - 1] = dfa_top;
             sp += 1;
@@ -539,7 +724,7 @@ public:
     }
     POA_HD void dfa_pop() {
         sp -= 1;
-        if (sp != 0) dfa_top = W.stack[sp - 1];
+        if (sp != 0) dfa_top = spec ? sl.dstack[(sp - 1) * sl.stride] : W.stack[sp - 1];
     }
 
     POA_HD Event dfa_extend() {
@@ -555,6 +740,7 @@ public:
             }
         }
         while (sp != 0) {
+            if (spec && (sl.flags & SPF_COMPLEX)) break;
             ExStackEntry& parent = dfa_top;
             const uint32_t cend = gld(&G.succ_off[parent.row + 1]);
             bool again = false;
@@ -641,17 +827,19 @@ public:
         P.w1 = P.sum = 0; P.ta = P.tb = P.tc = EX_INF;
         if (!P.on) return;
         const uint32_t x = gld(&G.exit_idx[P.ex]);
-        const uint64_t* bits = W.reached + (uint64_t)x * W.wpn;
-        P.sum = W.rsum[(uint64_t)x * W.swpn];
-        P.w1 = bits[P.wi];
-        if (P.t) P.ta = *cell(P.ex, P.t - 1, EX_ST_M);
-        P.tb = *cell(P.ex, P.t, EX_ST_M);
-        P.tc = *cell(P.ex, P.t + 1, EX_ST_M);
+        P.sum = rsw(x, 0);
+        P.w1 = rword(x, P.wi);
+        const uint32_t ia = cix(P.ex, P.t ? P.t - 1 : 0, EX_ST_M), ib = cix(P.ex, P.t, EX_ST_M), ic = cix(P.ex, P.t + 1, EX_ST_M);
+        const uint32_t va = W.T[ia], vb = W.T[ib], vc = W.T[ic];
+        if (P.t) P.ta = va;
+        P.tb = vb; P.tc = vc;
+        if (spec && sl.n_w) { if (P.t) P.ta = ovl(ia, va); P.tb = ovl(ib, vb); P.tc = ovl(ic, vc); }
     }
     // 0: can improve (not pruned); 2: pruned; 3: something the generic code has to look at (a reached cell without a score).
     // reached.rs:38-255 specialised to tmin == tmax.
     POA_HD uint32_t probe_decide(const Probe& P, uint32_t g, uint32_t st) {
-        if (!P.on || P.sum == 0) return 0;          // no bubble to test / nothing reached at the exit yet (reached.rs:52-54)
+        if (!P.on) return 0;                        // no bubble to test
+        if (P.sum == 0) { if (spec) note_marks(gld(&G.exit_idx[P.ex]), 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
         const uint32_t t = P.t, wi = P.wi, ex = P.ex;
         uint32_t prev = EX_NIL, nxt = EX_NIL;
         const bool at_t = (P.w1 >> (t & 63)) & 1;
@@ -662,9 +850,18 @@ public:
         const uint64_t hi = (t & 63) != 63 ? (P.w1 & (~0ull << ((t & 63) + 1))) : 0ull;
         if (hi) nxt = wi * 64 + (uint32_t)ctz64(hi);
         else if (wi + 1 < W.wpn && (P.sum >> (wi + 1))) nxt = reached_from(ex, (wi + 1) * 64);
+        // what the decision read of the exit row: the marks between the two neighbours and the scores at them (reached at t:
+        // the neighbour above is not looked at, reached.rs:139)
+        if (spec) {
+            note_marks(gld(&G.exit_idx[ex]), prev == EX_NIL ? 0u : prev, at_t ? t : nxt);
+            if (prev != EX_NIL && prev < W.pitch) note_cell(cix(ex, prev, EX_ST_M));
+            if (at_t) note_cell(cix(ex, t, EX_ST_M));
+            else if (nxt != EX_NIL && nxt < W.pitch) note_cell(cix(ex, nxt, EX_ST_M));
+        }
         // scores of the two neighbours: next to t they are loaded already; else both loads go out together
-        const uint32_t lq = *cell(ex, prev != EX_NIL && prev < W.pitch ? prev : t, EX_ST_M);
-        const uint32_t rq = *cell(ex, nxt != EX_NIL && nxt < W.pitch ? nxt : t, EX_ST_M);
+        const uint32_t iq = cix(ex, prev != EX_NIL && prev < W.pitch ? prev : t, EX_ST_M), jq = cix(ex, nxt != EX_NIL && nxt < W.pitch ? nxt : t, EX_ST_M);
+        uint32_t lq = W.T[iq], rq = W.T[jq];
+        if (spec && sl.n_w) { lq = ovl(iq, lq); rq = ovl(jq, rq); }
         uint32_t ls = 0, rs = 0;
         if (prev != EX_NIL) ls = prev + 1 == t ? P.ta : lq;
         if (nxt != EX_NIL) rs = nxt == t + 1 ? P.tc : (nxt < W.pitch ? rq : EX_INF);
@@ -718,13 +915,21 @@ public:
             if (gld(&G.sym[c]) == seq[j]) kind = 2;
         }
         // ---- every load of the step, before any use ----
-        const uint32_t own = *cell(v, j, st);
-        uint32_t t0, t1, t2 = EX_INF;
-        if (st == EX_ST_M) { t0 = *cell(c, j + 1, EX_ST_M); t1 = *cell(v, j + 1, EX_ST_I); t2 = *cell(c, j, EX_ST_D); }
-        else if (st == EX_ST_I) { t0 = *cell(v, j, EX_ST_M); t1 = j < L ? *cell(v, j + 1, EX_ST_I) : EX_INF; }
-        else { t0 = *cell(v, j, EX_ST_M); t1 = *cell(c, j, EX_ST_D); }
+        const uint32_t i_own = cix(v, j, st);
+        uint32_t i0, i1, i2 = i_own;
+        if (st == EX_ST_M) { i0 = cix(c, j + 1, EX_ST_M); i1 = cix(v, j + 1, EX_ST_I); i2 = cix(c, j, EX_ST_D); }
+        else if (st == EX_ST_I) { i0 = cix(v, j, EX_ST_M); i1 = cix(v, j < L ? j + 1 : j, EX_ST_I); }
+        else { i0 = cix(v, j, EX_ST_M); i1 = cix(c, j, EX_ST_D); }
+        uint32_t own = W.T[i_own];
+        uint32_t t0 = W.T[i0], t1 = W.T[i1], t2 = st == EX_ST_M ? W.T[i2] : EX_INF;
         probe_load(P);
         probe_load(Q);
+        if (spec) {
+            // (the probes note what they looked at when they decide)
+            note_cell(i_own); note_cell(i0); if (st != EX_ST_I || j < L) note_cell(i1); if (st == EX_ST_M) note_cell(i2);
+            if (sl.n_w) { own = ovl(i_own, own); t0 = ovl(i0, t0); t1 = ovl(i1, t1); if (st == EX_ST_M) t2 = ovl(i2, t2); }
+        }
+        if (st == EX_ST_I && j >= L) t1 = EX_INF;
         n_fast += 1;
         if (g > own) return 1;                      // stale (astar.rs:146)
         const uint32_t r = probe_decide2(P, Q, g, st);
@@ -740,23 +945,23 @@ public:
         if (err) return false;
         const uint32_t c = F.c;
         if (st == EX_ST_I) {
-            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
+            if (g < F.t0) { wr(v, j, EX_ST_M, g); queue_state(v, j, EX_ST_M, g); }
             const uint32_t ns = g + C.e;
-            if (j < L && ns < F.t1) { *cell(v, j + 1, EX_ST_I) = ns; queue_state(v, j + 1, EX_ST_I, ns); }
+            if (j < L && ns < F.t1) { wr(v, j + 1, EX_ST_I, ns); queue_state(v, j + 1, EX_ST_I, ns); }
             return false;
         }
         if (st == EX_ST_D) {
-            if (g < F.t0) { *cell(v, j, EX_ST_M) = g; queue_state(v, j, EX_ST_M, g); }
+            if (g < F.t0) { wr(v, j, EX_ST_M, g); queue_state(v, j, EX_ST_M, g); }
             const uint32_t ns = g + C.e;
-            if (ns < F.t1) { *cell(c, j, EX_ST_D) = ns; queue_state(c, j, EX_ST_D, ns); }
+            if (ns < F.t1) { wr(c, j, EX_ST_D, ns); queue_state(c, j, EX_ST_D, ns); }
             return false;
         }
         if (F.kind == 1) {
             // the only successor mismatches -> expand_mismatch (gap_affine.rs:393-430), then the extension has nothing left
             const uint32_t nm = g + C.x, ng = g + C.o + C.e;
-            if (nm < F.t0) { *cell(c, j + 1, EX_ST_M) = nm; queue_state(c, j + 1, EX_ST_M, nm); }
-            if (ng < F.t1) { *cell(v, j + 1, EX_ST_I) = ng; queue_state(v, j + 1, EX_ST_I, ng); }
-            if (ng < F.t2) { *cell(c, j, EX_ST_D) = ng; queue_state(c, j, EX_ST_D, ng); }
+            if (nm < F.t0) { wr(c, j + 1, EX_ST_M, nm); queue_state(c, j + 1, EX_ST_M, nm); }
+            if (ng < F.t1) { wr(v, j + 1, EX_ST_I, ng); queue_state(v, j + 1, EX_ST_I, ng); }
+            if (ng < F.t2) { wr(c, j, EX_ST_D, ng); queue_state(c, j, EX_ST_D, ng); }
             return false;
         }
         // Greedy extension along single-successor rows (dfa.rs:138-250).  A parent with one successor has nothing left once
@@ -767,8 +972,9 @@ public:
         for (;;) {
             // here: cc is the single successor of cv, not the end row, cj < L, sym(cc) == seq[cj]
             const uint32_t nj = cj + 1;
+            if (spec && (sl.flags & SPF_COMPLEX)) break;   // (the lane is cut off: whatever it does from here on is discarded)
             if (!(g < tm)) break;                          // already there with this score or better: not extended (dfa.rs:242)
-            *cell(cc, nj, EX_ST_M) = g;
+            wr(cc, nj, EX_ST_M, g);
             // what the tip needs next: its own successor, its bubble test, and what a mismatch there relaxes
             const uint32_t s0 = gld(&G.succ_off[cc]), s1 = gld(&G.succ_off[cc + 1]);
             const uint32_t nc = s1 - s0 == 1 ? gld(&G.succ[s0]) : EX_NIL;
@@ -777,7 +983,14 @@ public:
             const bool walk_on = shaped && nc != EX_NIL && nc != G.end_row && nj < L && nj + 2 < W.pitch;
             uint32_t n0 = EX_INF, n1 = EX_INF, n2 = EX_INF;
             if (shaped) { probe_load(P); probe_load(Q); }
-            if (walk_on) { n0 = *cell(nc, nj + 1, EX_ST_M); n1 = *cell(cc, nj + 1, EX_ST_I); n2 = *cell(nc, nj, EX_ST_D); }
+            if (walk_on) {
+                const uint32_t j0 = cix(nc, nj + 1, EX_ST_M), j1 = cix(cc, nj + 1, EX_ST_I), j2 = cix(nc, nj, EX_ST_D);
+                n0 = W.T[j0]; n1 = W.T[j1]; n2 = W.T[j2];
+                if (spec) {
+                    note_cell(j0); note_cell(j1); note_cell(j2);
+                    if (sl.n_w) { n0 = ovl(j0, n0); n1 = ovl(j1, n1); n2 = ovl(j2, n2); }
+                }
+            }
             uint32_t pr = shaped ? probe_decide2(P, Q, g, EX_ST_M) : 3u;
             if (pr == 3) pr = prune(g, cc, nj, EX_ST_M) ? 2u : 0u;
             if (err) break;
@@ -792,9 +1005,9 @@ public:
             }
             if (gld(&G.sym[nc]) != seq[nj]) {
                 const uint32_t nm = g + C.x, ng = g + C.o + C.e;
-                if (nm < n0) { *cell(nc, nj + 1, EX_ST_M) = nm; queue_state(nc, nj + 1, EX_ST_M, nm); }
-                if (ng < n1) { *cell(cc, nj + 1, EX_ST_I) = ng; queue_state(cc, nj + 1, EX_ST_I, ng); }
-                if (ng < n2) { *cell(nc, nj, EX_ST_D) = ng; queue_state(nc, nj, EX_ST_D, ng); }
+                if (nm < n0) { wr(nc, nj + 1, EX_ST_M, nm); queue_state(nc, nj + 1, EX_ST_M, nm); }
+                if (ng < n1) { wr(cc, nj + 1, EX_ST_I, ng); queue_state(cc, nj + 1, EX_ST_I, ng); }
+                if (ng < n2) { wr(nc, nj, EX_ST_D, ng); queue_state(nc, nj, EX_ST_D, ng); }
                 break;
             }
             cj = nj; cc = nc; tm = n0;
@@ -917,6 +1130,136 @@ public:
         R.num_queued = num_queued; R.num_visited = num_visited; R.num_pruned = num_pruned;
         return R;
     }
+
+    // ---- log mode: one lane's share of a step (poa_psearch.hpp) ------------------------------------------------------------
+    // Processes the entry (g, v, j) popped from stack (f, st) and the entries its expansion puts in front of the next entry
+    // of that stack, at most `rmax` of them, reading the table as it stands (plus the lane's own log) and writing only to the
+    // log.  sl.flags says how it ended; the counters of the search are left untouched (sl.dq / dv / dp carry the deltas).
+    POA_HD void spec_group(uint32_t g, uint32_t v, uint32_t j, uint32_t st, uint32_t f, uint32_t rmax, ExactResult& R, uint32_t& end_score,
+                           bool use_fast = true) {
+        sl.n_w = sl.n_m = sl.n_p = sl.n_pd = 0; sl.flags = 0; sl.n_rc = sl.n_rm = 0; sl.n_ent = 0;
+        sl.cur_f = f; sl.root_st = st;
+        const uint32_t q0 = num_queued, v0 = num_visited, p0 = num_pruned;
+        spec = true;
+        for (;;) {
+            // (an entry after the first that does not fit the logs is put back: it and what else is pending go to the queue)
+            const SpecLane snap = sl;
+            const uint32_t q1 = num_queued, v1 = num_visited, p1 = num_pruned;
+            if (sl.n_ent) spec_pending_pop(g, v, j, st);
+            FastItem F{0, 0, 0, 0, 0};
+            uint32_t sk = use_fast ? inspect_fast(g, v, j, st, F) : 3u;
+            if (sk == 3 && !err && !(sl.flags & SPF_COMPLEX)) sk = inspect_skip(g, v, j, st);
+            bool found = false;
+            if (!err && !(sl.flags & SPF_COMPLEX)) {
+                if (sk == 2) num_pruned += 1;
+                if (sk == 0) found = F.kind ? process_fast(g, v, j, st, F, R, end_score) : process_popped(g, v, j, st, R, end_score);
+            }
+            if (err || (sl.flags & SPF_COMPLEX)) {
+                if (sl.n_ent == 0) break;
+                sl = snap; err = EX_OK; num_queued = q1; num_visited = v1; num_pruned = p1;
+                sl.flags |= SPF_LEFTOVER;
+                break;
+            }
+            sl.n_ent += 1;
+            if (found) { sl.flags |= SPF_FOUND; break; }
+            if (sl.n_pd == 0) break;
+            if (sl.n_ent >= rmax) { sl.flags |= SPF_LEFTOVER; break; }
+        }
+        spec = false;
+        if (err) { sl.flags |= SPF_COMPLEX; err = EX_OK; }   // the sequential code meets the same condition and reports it
+        sl.dq = num_queued - q0; sl.dv = num_visited - v0; sl.dp = num_pruned - p0;
+        num_queued = q0; num_visited = v0; num_pruned = p0;
+    }
+    // did this lane read a cell or a mark that `o` (an earlier lane of the step) logged a write to?
+    POA_HD bool spec_reads_what(const SpecLane& o) const {
+        for (uint32_t a = 0; a < sl.n_rc; ++a)
+            for (uint32_t b = 0; b < o.n_w; ++b)
+                if (sl.rc[a * sl.stride] == o.w_idx[b * o.stride]) return true;
+        for (uint32_t a = 0; a < sl.n_rm; ++a)
+            for (uint32_t b = 0; b < o.n_m; ++b)
+                if (sl.rm_x[a * sl.stride] == o.m_x[b * o.stride] && sl.rm_lo[a * sl.stride] <= o.m_off[b * o.stride] && o.m_off[b * o.stride] <= sl.rm_hi[a * sl.stride]) return true;
+        return false;
+    }
+    // commit of one lane's log: cell writes, marks, counters (queue pushes are the caller's: they need the lanes' order)
+    POA_HD void spec_commit(const SpecLane& l) {
+        for (uint32_t k = 0; k < l.n_w; ++k) W.T[l.w_idx[k * l.stride]] = l.w_val[k * l.stride];
+        for (uint32_t k = 0; k < l.n_m; ++k) mark_word(l.m_x[k * l.stride], l.m_off[k * l.stride]);
+        num_queued += l.dq; num_visited += l.dv; num_pruned += l.dp;
+    }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+    uint32_t par_steps = 0, par_seq = 0, par_entries = 0, par_cut_complex = 0, par_cut_conflict = 0, par_cut_leftover = 0;   // statistics
+    uint32_t par_hist[65] = {}, par_hist_conf[65] = {}, par_hist_nb[65] = {};
+    // The schedule of the wave kernel poa_psearch.hpp, one lane after the other (host build: its executable specification;
+    // tests/test_exact_replay.py diffs it against the oracle).  A step takes the top `lanes` entries of the current stack;
+    // every one is processed in log mode against the table as the step found it; the step commits the lanes before the first
+    // one that (a) read what an earlier lane wrote, or (b) needs the sequential code; a lane that ends the search or leaves
+    // entries pending is the last one committed.  A first lane that needs the sequential code is run by it, alone.
+    ExactResult run_parallel(uint32_t lanes, uint32_t rmax, bool use_fast = true) {
+        ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+        push_initial_states();
+        uint32_t end_score = EX_INF;
+        bool found = false;
+        if (lanes > 63) lanes = 63;
+        struct LaneBuf { uint32_t w_idx[SP_KW], w_val[SP_KW], m_x[SP_KM], m_off[SP_KM], rc[SP_KRC], rm_x[SP_KRM], rm_lo[SP_KRM], rm_hi[SP_KRM]; ExU4 p[SP_KP]; ExStackEntry ds[SP_KDS]; };
+        LaneBuf* buf = new LaneBuf[64];
+        SpecLane* ls = new SpecLane[64];
+        ExactResult* rs = new ExactResult[64];
+        uint32_t* es = new uint32_t[64];
+        while (!found && !err) {
+            uint32_t st; BqDesc d;
+            if (!bq_current(st, d)) { err = EX_PANIC; break; }
+            par_steps += 1;
+            const uint32_t f = layer_min;
+            const uint32_t nb = d.n_top < lanes ? d.n_top : lanes;
+            const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
+            const uint32_t prev_chunk = ch[0].x;
+            uint32_t n_commit = 0;       // lanes committed
+            bool seq0 = false;
+            for (uint32_t i = 0; i < nb; ++i) {
+                const ExU4 e = ch[d.n_top - i];
+                sl = SpecLane();
+                sl.w_idx = buf[i].w_idx; sl.w_val = buf[i].w_val; sl.m_x = buf[i].m_x; sl.m_off = buf[i].m_off; sl.p = buf[i].p; sl.stride = 1;
+                sl.rc = buf[i].rc; sl.rm_x = buf[i].rm_x; sl.rm_lo = buf[i].rm_lo; sl.rm_hi = buf[i].rm_hi; sl.dstack = buf[i].ds;
+                rs[i] = R; es[i] = end_score;
+                spec_group(e.x, e.y, e.z, st, f, rmax, rs[i], es[i], use_fast);
+                ls[i] = sl;
+                bool cut_before = (sl.flags & SPF_COMPLEX) != 0;
+                for (uint32_t a = 0; a < i && !cut_before; ++a) {
+                    cut_before = spec_reads_what(ls[a]);
+                }
+                if (cut_before) { seq0 = i == 0; if (i) { if (sl.flags & SPF_COMPLEX) par_cut_complex += 1; else { par_cut_conflict += 1; par_hist_conf[i] += 1; } } break; }
+                n_commit = i + 1; par_entries += sl.n_ent;
+                if (sl.flags & SPF_LEFTOVER) par_cut_leftover += 1;
+                if (sl.flags & (SPF_FOUND | SPF_LEFTOVER)) break;
+            }
+            if (seq0) {
+                // the sequential code for the top entry
+                par_seq += 1;
+                const ExU4 e = ch[d.n_top];
+                bq_drop(st, d, 1, prev_chunk);
+                const uint32_t sk = inspect_skip(e.x, e.y, e.z, st);
+                if (sk == 2) num_pruned += 1;
+                if (sk == 0 && !err) found = process_popped(e.x, e.y, e.z, st, R, end_score);
+                continue;
+            }
+            par_hist[n_commit] += 1; par_hist_nb[nb] += 1;
+            bq_drop(st, d, n_commit, prev_chunk);
+            for (uint32_t i = 0; i < n_commit; ++i) {
+                spec_commit(ls[i]);
+                // what the lane left pending goes on the queue in its push order (only the last lane can have any)
+                for (uint32_t k = 0; k < ls[i].n_pd; ++k) bq_push(ls[i].pd_key[k] >> 2, ls[i].pd_key[k] & 3u, ls[i].pd_score[k], ls[i].pd_row[k], ls[i].pd_off[k]);
+                for (uint32_t k = 0; k < ls[i].n_p; ++k) { const ExU4 q = ls[i].p[k]; bq_push(q.w >> 2, q.w & 3u, q.x, q.y, q.z); }
+                if (ls[i].flags & SPF_FOUND) { found = true; R.end_row = rs[i].end_row; R.end_off = rs[i].end_off; end_score = es[i]; }
+            }
+        }
+        delete[] buf; delete[] ls; delete[] rs; delete[] es;
+        R.status = err ? err : (found ? EX_OK : EX_PANIC);
+        R.score = end_score;
+        R.num_queued = num_queued; R.num_visited = num_visited; R.num_pruned = num_pruned;
+        return R;
+    }
+#endif
 };
 using ExactSearch = ExactSearchT<0>;
 

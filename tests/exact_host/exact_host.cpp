@@ -14,13 +14,15 @@
 
 using namespace poa_amd;
 
-static uint32_t g_batch = 0, g_win = 0;
+static uint32_t g_batch = 0, g_win = 0, g_par_lanes = 0, g_par_rmax = 4, g_par_fast = 1;
 
 extern "C" {
 
 // 0: linked-list queue (ExactSearch::run); n > 0: bucket queue stepped in batches of n (ExactSearch::run_buckets)
 void exact_host_set_batch(uint32_t n) { g_batch = n; }
 void exact_host_set_window(uint32_t w) { g_win = w; }  // 0: a window that always suffices
+// lanes > 0: ExactSearch::run_parallel(lanes, rmax) — the step schedule of poa_psearch.hpp (entries of a stack expanded at once)
+void exact_host_set_parallel(uint32_t lanes, uint32_t rmax, uint32_t use_fast) { g_par_lanes = lanes; g_par_rmax = rmax; g_par_fast = use_fast; }
 
 // returns status (EX_*), or negative POA_ERR_* for graph errors.
 // planes (optional): M/I/D as [node][len+1]; out[0..3] = score, num_queued, num_visited, num_pruned
@@ -51,7 +53,7 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     // bucket queue of the wave search (batch > 0): a small ring so that the window logic is exercised
     std::vector<uint32_t> bq_desc;
     std::vector<ExU4> bq_chunks;
-    if (g_batch) {
+    if (g_batch || g_par_lanes) {
         uint32_t win = 64;
         const uint32_t need = 2 * (std::max<uint32_t>(x, (uint32_t)o + e) + o + (uint32_t)(g.n + 2) * e) + 8;
         while (win < need) win *= 2;
@@ -63,9 +65,21 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     ExactCosts EC{x, o, e, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0};
     if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
     ExactSearch S(G, W, seq, len, EC);
-    ExactResult R = g_batch ? S.run_buckets(g_batch) : S.run();
+    ExactResult R = g_par_lanes ? S.run_parallel(g_par_lanes, g_par_rmax, g_par_fast != 0) : g_batch ? S.run_buckets(g_batch) : S.run();
     if (getenv("EXH_VERBOSE")) fprintf(stderr, "chunks used %u of %u, status %u, fast-path tests %u, queued %u\n", S.bq_chunk_top, W.bq_chunk_cap, R.status, S.n_fast, R.num_queued);
+    if (getenv("EXH_VERBOSE") && g_par_lanes) {
+        fprintf(stderr, "  lanes committed per step:"); for (int k = 0; k < 65; ++k) if (S.par_hist[k]) fprintf(stderr, " %d:%u", k, S.par_hist[k]); fprintf(stderr, "\n");
+        fprintf(stderr, "  conflict cut at lane:"); for (int k = 0; k < 65; ++k) if (S.par_hist_conf[k]) fprintf(stderr, " %d:%u", k, S.par_hist_conf[k]); fprintf(stderr, "\n");
+        fprintf(stderr, "  entries offered per step:"); for (int k = 0; k < 65; ++k) if (S.par_hist_nb[k]) fprintf(stderr, " %d:%u", k, S.par_hist_nb[k]); fprintf(stderr, "\n");
+    }
+    if (getenv("EXH_VERBOSE") && g_par_lanes)
+        fprintf(stderr, "parallel schedule: %u steps (%u sequential), %u entries in log mode; cuts: %u complex, %u conflict, %u leftover; visited %u pruned %u\n",
+                S.par_steps, S.par_seq, S.par_entries, S.par_cut_complex, S.par_cut_conflict, S.par_cut_leftover, R.num_visited, R.num_pruned);
 #if defined(POA_EXACT_DIAG)
+    if (getenv("EXH_VERBOSE") && g_par_lanes) {
+        fprintf(stderr, "  why complex: read cells %u, mark ranges %u, cell writes %u, marks %u, pushes %u, pending %u, dfa stack %u, prio %u\n", S.why_complex[1], S.why_complex[2],
+                S.why_complex[3], S.why_complex[4], S.why_complex[5], S.why_complex[6], S.why_complex[7], S.why_complex[9]);
+    }
     if (getenv("EXH_VERBOSE")) {
         const char* why[8] = {"stale/pruned on the fast path", "several successors", "end row / misc", "bubble shape", "Match special", "probe undecided", "fast expand", "fast greedy walk"};
         for (int r = 0; r < 8; ++r) fprintf(stderr, "  %-32s M %8u  D %8u  I %8u\n", why[r], S.diag[r][0], S.diag[r][1], S.diag[r][2]);

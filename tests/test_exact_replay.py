@@ -32,16 +32,24 @@ def harness():
     X.exact_host_run.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [C.c_uint8] * 3 + [C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     X.exact_host_bubbles.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp] * 5 + [C.c_uint32]
     X.exact_host_set_batch.argtypes = [C.c_uint32]
+    X.exact_host_set_parallel.argtypes = [C.c_uint32] * 3
     return X
 
 
-@pytest.fixture(params=[0, 1, 7, 64], ids=["linked_list_queue", "buckets_batch1", "buckets_batch7", "buckets_batch64"])
+@pytest.fixture(params=[0, 1, 7, 64, (63, 4, 1), (5, 1, 1), (63, 8, 0), (2, 3, 1)],
+                ids=["linked_list_queue", "buckets_batch1", "buckets_batch7", "buckets_batch64", "parallel_63x4", "parallel_5x1",
+                     "parallel_63x8_generic_code", "parallel_2x3"])
 def queue_variant(request, harness):
     """0: ExactSearch::run (linked-list queue, the one-search-per-lane kernel); n: ExactSearch::run_buckets(n), the
-    step schedule of the wave-per-query kernel (poa_wsearch.hpp) over the bucket queue."""
-    harness.exact_host_set_batch(request.param)
+    step schedule of the wave-per-query kernel (poa_wsearch.hpp) over the bucket queue; (lanes, rmax, fast):
+    ExactSearch::run_parallel, the schedule of poa_psearch.hpp (the top entries of a stack expanded at once in log mode)."""
+    if isinstance(request.param, tuple):
+        harness.exact_host_set_parallel(*request.param)
+    else:
+        harness.exact_host_set_batch(request.param)
     yield request.param
     harness.exact_host_set_batch(0)
+    harness.exact_host_set_parallel(0, 4, 1)
 
 
 def _oracle_table(oracle, og, q, costs, heur, prune, n):
