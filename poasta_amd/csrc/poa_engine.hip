@@ -861,7 +861,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < pp.chunk_cap) pp.chunk_cap = (uint32_t)v; }
                 pp.win = win;
                 pp.counters = b->d_ex_counters.p;
-                pp.max_lanes = 63;
+                pp.max_lanes = 63;   // (capped at the group's lanes below)
                 if (const char* lv = getenv("POA_PS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) pp.max_lanes = (uint32_t)v; }
                 pp.rmax = 8;
                 if (const char* lv = getenv("POA_PS_ROUNDS")) { const int v = atoi(lv); if (v >= 1 && v <= 64) pp.rmax = (uint32_t)v; }
@@ -870,26 +870,33 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                     HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
                     pp.prof = b->d_ex_prof.p;
                 }
-                // LDS of a block: the staged graph (shared by its waves) + per wave the descriptor ring and the read sets / conflict
-                // table of the step.  As many waves per block as fit 160 KB, at most 8 (two per SIMD: the step keeps a lane's logs
-                // and read sets in ~200 registers).
+                // Lanes per query: a step commits a dozen lanes on the benchmark's reads, and the kernel waits for memory more than it
+                // issues — so four searches share a wave (16 lanes each), all stepping through one instruction stream.
+                uint32_t group = 16;
+                if (const char* gv = getenv("POA_PS_GROUP")) { const int v = atoi(gv); if (v == 16 || v == 32 || v == 64) group = (uint32_t)v; }
+                const uint32_t qpw = 64 / group;
+                pp.group = group;
+                if (pp.max_lanes > group - 1) pp.max_lanes = group - 1;
+                // LDS of a block: the staged graph (shared by its waves) + per wave the descriptor rings of its queries and the
+                // logs / read sets / conflict tables of the step.  As many waves per block as fit 160 KB, at most 8 (two per SIMD:
+                // the kernel keeps a lane's search state in ~250 registers).
                 const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 160u * 1024u);
-                const uint64_t ring_b = ((uint64_t)3 * win * 4 + 15) & ~15ull;
+                const uint64_t ring_b = ((uint64_t)qpw * 3 * win * 4 + 15) & ~15ull;
                 bool ring_lds = ring_b + ps_lds_bytes() <= lds_budget && !getenv("POA_WS_RING_GLOBAL");
                 uint64_t per_wave = (ring_lds ? ring_b : 0) + ps_lds_bytes();
                 bool stage = graph_lds + per_wave <= lds_budget;
                 if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
-                if (!stage && ring_lds && per_wave > lds_budget) { ring_lds = false; per_wave = ps_lds_bytes(); }
                 uint32_t wpb = (uint32_t)std::min<uint64_t>(8, (lds_budget - (stage ? graph_lds : 0)) / per_wave);
                 if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && (uint32_t)v <= wpb) wpb = (uint32_t)v; }
-                if (wpb < 1) return fail(POA_ERR_UNSUPPORTED, "exact replay: the step's read sets do not fit the LDS");
+                if (wpb < 1) return fail(POA_ERR_UNSUPPORTED, "exact replay: the step's logs do not fit the LDS");
                 pp.graph_lds = stage ? graph_lds : 0;
                 pp.waves_per_block = wpb;
                 pp.ring_global = ring_lds ? nullptr : b->d_ex_head.p;   // [slots * 3 * ex_n_prio] holds slots * 3 * win
                 const uint32_t lds_bytes = pp.graph_lds + (uint32_t)(wpb * per_wave);
                 const void* kfn = reinterpret_cast<const void*>(poa_psearch_kernel);
                 if (lds_bytes > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                uint32_t n_blocks = (ch.count + wpb - 1) / wpb;
+                const uint32_t per_block = wpb * qpw;
+                uint32_t n_blocks = (ch.count + per_block - 1) / per_block;
                 pp.work_counter = nullptr; pp.order = nullptr;
                 int per_cu = 1, cus = 256;
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
@@ -1109,8 +1116,9 @@ int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out) {
         HIP_TRY(hipMemcpy(pr.data(), b->d_ex_prof.p, pr.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long sum[8] = {0};
         for (size_t i = 0; i < pr.size(); ++i) sum[i & 7] += pr[i];
-        fprintf(stderr, "[ws prof] cycles: queue+entries %llu, parallel test %llu, drop %llu, fast expand %llu (%llu), generic %llu (%llu)\n",
-                sum[0], sum[1], sum[2], sum[3], sum[5], sum[4], sum[6]);
+        // wave search: queue+entries, parallel test, drop, fast expand, generic, (counts: fast, generic); parallel-step search: queue+entries,
+        // log-mode phase, conflict test, commit, sequential code, pushes, (counts: sequential steps, lanes committed)
+        fprintf(stderr, "[ws prof] cycles / counts: %llu %llu %llu %llu %llu %llu %llu %llu\n", sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[6], sum[7]);
     }
     return POA_OK;
 }

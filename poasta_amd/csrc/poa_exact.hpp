@@ -113,12 +113,13 @@ struct ExactCosts {
 // log.  Afterwards the step finds the first lane that read something an earlier lane of the step logged a write to
 // (cell by cell, mark by mark), commits the logs of the lanes before it in lane order — exactly the writes and pushes the
 // reference's sequential loop makes — and leaves the rest of the stack for the next step.
-constexpr uint32_t SP_KW = 12;   // cell writes a lane may log per step
-constexpr uint32_t SP_KM = 8;    // reached marks
-constexpr uint32_t SP_KP = 12;   // queue pushes (those that do not come back within the lane's own group)
+constexpr uint32_t SP_KW = 8;    // cell writes a lane may log per step
+constexpr uint32_t SP_KM = 6;    // reached marks
+constexpr uint32_t SP_KP = 8;    // queue pushes (those that do not come back within the lane's own group)
 constexpr uint32_t SP_KPD = 4;   // pending entries of the lane's own group
-constexpr uint32_t SP_KRC = 32;  // cells whose value a lane's decisions depended on
-constexpr uint32_t SP_KRM = 6;   // ranges of a reached set they depended on
+constexpr uint32_t SP_KRC = 24;  // cells whose value a lane's decisions depended on (kept as 16-bit hashes of their index:
+                                 // a chance match only ends a step early)
+constexpr uint32_t SP_KRM = 4;   // exits whose reached set they depended on (one range each)
 constexpr uint32_t SP_KDS = 4;   // depth of the greedy extension's stack (parents with successors left)
 enum : uint32_t {
     SPF_COMPLEX = 1,    // the lane met something the log mode does not do (log / box overflow, an error, a greedy extension
@@ -138,14 +139,17 @@ struct SpecLane {
     uint32_t pd_key[SP_KPD] = {}, pd_score[SP_KPD] = {}, pd_row[SP_KPD] = {}, pd_off[SP_KPD] = {};   // in push order
     // what the lane read: cells (index into the table) and ranges [lo, hi] of the reached set of exit x — element k at base[k * stride]
     uint32_t n_rc = 0, n_rm = 0;
-    uint32_t* rc = nullptr; uint32_t* rm_x = nullptr; uint32_t* rm_lo = nullptr; uint32_t* rm_hi = nullptr;
+    uint16_t* rc = nullptr; uint32_t* rm_x = nullptr; uint32_t* rm_lo = nullptr; uint32_t* rm_hi = nullptr;
+    // which cells / words of the reached sets the lane has logged writes to, hashed into 32 bits: a read that misses
+    // them (nearly every read) skips the overlay
+    uint32_t wmask = 0, mmask = 0;
 };
 
 // Address-space tags of the two tables a kernel may stage in LDS (the graph arrays; the queue's descriptor ring).  A pointer
 // that may be global or LDS compiles to FLAT loads, which wait for every outstanding vector-memory AND LDS operation
 // (they count on both counters): one such load in the middle of a batch of table reads serialises the batch.  With the
 // tag the access is a ds_read / ds_write and overlaps with the global loads in flight.
-enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4 };   // (4: the read sets of the log mode, SpecLane::rc / rm_*)
+enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4 };   // (4: logs and read sets of the log mode: SpecLane::w_*, m_*, rc, rm_*)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T> __device__ inline __attribute__((always_inline)) T ex_lds_load(const T* p) {
     return *(const __attribute__((address_space(3))) T*)p;
@@ -176,18 +180,20 @@ public:
 #endif
         *p = v;
     }
-    POA_HD uint32_t sld(const uint32_t* p) const {
+    template <class T> POA_HD T sld(const T* p) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr ((AS & EX_AS_READSET_LDS) != 0) return ex_lds_load(p);
 #endif
         return *p;
     }
-    POA_HD void sst(uint32_t* p, uint32_t v) const {
+    template <class T> POA_HD void sst(T* p, T v) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr ((AS & EX_AS_READSET_LDS) != 0) { ex_lds_store(p, v); return; }
 #endif
         *p = v;
     }
+    static POA_HD uint16_t sp_hash16(uint32_t ix) { return (uint16_t)((ix * 0x9E3779B1u) >> 16); }
+    static POA_HD uint32_t sp_bit(uint32_t key) { return 1u << ((key * 0x9E3779B1u) >> 27); }
     const ExactGraph& G;
     ExactWork& W;
     const uint8_t* seq;
@@ -201,9 +207,27 @@ public:
     POA_HD ExactSearchT(const ExactGraph& g, ExactWork& w, const uint8_t* s, uint32_t len, ExactCosts c)
         : G(g), W(w), seq(s), L(len), C(c) {}
 
+    // a search object is reused for the next query of its wave / lane group
+    POA_HD void begin_query(const uint8_t* s, uint32_t len) {
+        seq = s; L = len; err = EX_OK;
+        layer_min = 0; n_layers = 0; pool_top = 0; num_queued = num_visited = num_pruned = 0;
+        bq_live = 0; bq_chunk_top = 0; bq_hi = 0; bq_free = EX_NIL;
+        sp = 0; dfa_visited = 0; dfa_score = 0; n_fast = 0; num_pruned_dfa = 0;
+    }
     // ---- log mode (see SpecLane) ---------------------------------------------------------------
     bool spec = false;
     SpecLane sl;
+#if defined(POA_PS_PROF_FINE)
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = 0;
+#endif
+#if defined(POA_PS_PROF_FINE) && defined(__HIP_DEVICE_COMPILE__)
+#define PF_START() do { pf_t = clock64(); } while (0)
+#define PF_TICK(k) do { const unsigned long long n_ = clock64(); pf[k] += n_ - pf_t; pf_t = n_; } while (0)
+#else
+#define PF_START() ((void)0)
+#define PF_TICK(k) ((void)0)
+#endif
+
 #if defined(POA_EXACT_DIAG)
     uint32_t why_complex[12] = {};
     void sp_flag(uint32_t f, uint32_t why = 0) { sl.flags |= f; why_complex[why] += 1; }
@@ -213,7 +237,7 @@ public:
     // a cell / a range of a reached set whose content the lane's decisions depend on
     POA_HD void note_cell(uint32_t ix) {
         if (sl.n_rc >= SP_KRC) { sp_flag(SPF_COMPLEX, 1); return; }
-        sst(&sl.rc[sl.n_rc * sl.stride], ix);
+        sst(&sl.rc[sl.n_rc * sl.stride], sp_hash16(ix));
         sl.n_rc += 1;
     }
     POA_HD void note_marks(uint32_t x, uint32_t lo, uint32_t hi) {
@@ -230,7 +254,8 @@ public:
     }
     // the lane's own logged value of cell `ix`, else v
     POA_HD uint32_t ovl(uint32_t ix, uint32_t v) const {
-        for (uint32_t k = 0; k < sl.n_w; ++k) if (sl.w_idx[k * sl.stride] == ix) v = sl.w_val[k * sl.stride];
+        if (!(sl.wmask & sp_bit(ix))) return v;
+        for (uint32_t k = 0; k < sl.n_w; ++k) if (sld(&sl.w_idx[k * sl.stride]) == ix) v = sld(&sl.w_val[k * sl.stride]);
         return v;
     }
     POA_HD uint32_t cix(uint32_t row, uint32_t off, uint32_t st) const { return ex_cell_index32(row, off, st, W.n_rows, W.pitch); }
@@ -247,23 +272,32 @@ public:
         if (!spec) { W.T[ix] = val; return; }
         // (append only — a later entry for the same cell wins, in the overlay and at the commit — so that the log can be cut back)
         if (sl.n_w >= SP_KW) { sp_flag(SPF_COMPLEX, 3); return; }
-        sl.w_idx[sl.n_w * sl.stride] = ix; sl.w_val[sl.n_w * sl.stride] = val;
+        sst(&sl.w_idx[sl.n_w * sl.stride], ix); sst(&sl.w_val[sl.n_w * sl.stride], val);
+        sl.wmask |= sp_bit(ix);
         sl.n_w += 1;
     }
     // words of the reached sets, with the lane's own logged marks
+    // (log mode: the sets do not change while the lanes of a step read them — the last word and the last summary word stay
+    // in registers: the generic pruning test asks for the same word again and again, reached.rs:67-170)
+    mutable uint32_t rc_x = EX_NIL, rc_wi = 0, rs_x = EX_NIL, rs_si = 0;
+    mutable uint64_t rc_w = 0, rs_w = 0;
     POA_HD uint64_t rword(uint32_t x, uint32_t wi) const {
-        uint64_t w = W.reached[(uint64_t)x * W.wpn + wi];
-        if (spec) for (uint32_t k = 0; k < sl.n_m; ++k) {
-            const uint32_t o = sl.m_off[k * sl.stride];
-            if (sl.m_x[k * sl.stride] == x && (o >> 6) == wi) w |= 1ull << (o & 63);
+        uint64_t w;
+        if (spec && rc_x == x && rc_wi == wi) w = rc_w;
+        else { w = W.reached[(uint64_t)x * W.wpn + wi]; if (spec) { rc_x = x; rc_wi = wi; rc_w = w; } }
+        if (spec && (sl.mmask & sp_bit(x))) for (uint32_t k = 0; k < sl.n_m; ++k) {
+            const uint32_t o = sld(&sl.m_off[k * sl.stride]);
+            if (sld(&sl.m_x[k * sl.stride]) == x && (o >> 6) == wi) w |= 1ull << (o & 63);
         }
         return w;
     }
     POA_HD uint64_t rsw(uint32_t x, uint32_t si) const {
-        uint64_t w = W.rsum[(uint64_t)x * W.swpn + si];
-        if (spec) for (uint32_t k = 0; k < sl.n_m; ++k) {
-            const uint32_t o = sl.m_off[k * sl.stride];
-            if (sl.m_x[k * sl.stride] == x && (o >> 12) == si) w |= 1ull << ((o >> 6) & 63);
+        uint64_t w;
+        if (spec && rs_x == x && rs_si == si) w = rs_w;
+        else { w = W.rsum[(uint64_t)x * W.swpn + si]; if (spec) { rs_x = x; rs_si = si; rs_w = w; } }
+        if (spec && (sl.mmask & sp_bit(x))) for (uint32_t k = 0; k < sl.n_m; ++k) {
+            const uint32_t o = sld(&sl.m_off[k * sl.stride]);
+            if (sld(&sl.m_x[k * sl.stride]) == x && (o >> 12) == si) w |= 1ull << ((o >> 6) & 63);
         }
         return w;
     }
@@ -322,9 +356,10 @@ public:
         if ((off >> 6) >= W.wpn) { err = EX_POOL_FULL; return; }
         EX_TRACE_REACH(row, off, off, 1);
         if (!spec) { mark_word(x, off); return; }
-        for (uint32_t k = 0; k < sl.n_m; ++k) if (sl.m_x[k * sl.stride] == x && sl.m_off[k * sl.stride] == off) return;
+        if (sl.mmask & sp_bit(x)) for (uint32_t k = 0; k < sl.n_m; ++k) if (sld(&sl.m_x[k * sl.stride]) == x && sld(&sl.m_off[k * sl.stride]) == off) return;
         if (sl.n_m >= SP_KM) { sp_flag(SPF_COMPLEX, 4); return; }
-        sl.m_x[sl.n_m * sl.stride] = x; sl.m_off[sl.n_m * sl.stride] = off;
+        sst(&sl.m_x[sl.n_m * sl.stride], x); sst(&sl.m_off[sl.n_m * sl.stride], off);
+        sl.mmask |= sp_bit(x);
         sl.n_m += 1;
     }
     POA_HD bool reached_any(uint32_t row) {  // !reached_offsets.is_empty()
@@ -894,48 +929,62 @@ public:
     }
 
     struct FastItem {
-        uint32_t kind;        // 0: generic path; 1: expands without a greedy match; 2: Match state whose only successor matches
-        uint32_t c;           // the single successor row
+        uint32_t kind;        // 0: generic path; 1: expands without a greedy match; 2: Match state whose first successor matches
+        uint32_t c, c1;       // the successor rows (c1 == EX_NIL: one successor)
         uint32_t t0, t1, t2;  // M: M[c][j+1], I[v][j+1], D[c][j];  I: M[v][j], I[v][j+1];  D: M[v][j], D[c][j]
+        uint32_t t3, t4;      // second successor — M: M[c1][j+1], D[c1][j];  D: D[c1][j]
     };
     // Test of a popped state: 0 goes on to process_fast; 1 stale; 2 pruned; 3 not this shape (F.kind == 0: inspect_skip decides).
+    // The shape: one or two successors, none of them the end row (an Insertion state: any), for a Match state query symbols left
+    // and a second successor that does not match; the bubbles decide only HOW the pruning test is made (probes, else the
+    // generic code).
     POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
         F.kind = 0;
         const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
-        // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341 — so a branching row is fine for it)
-        if (C.ends_free || (s1 - s0 != 1 && (st != EX_ST_I || s1 == s0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) { EXD(s1 - s0 != 1 ? 1 : 2, st); return 3; }
+        const uint32_t ns = s1 - s0;
+        // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341)
+        if (C.ends_free || ((ns == 0 || ns > 2) && (st != EX_ST_I || ns == 0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) { EXD(ns != 1 ? 1 : 2, st); return 3; }
         const uint32_t c = gld(&G.succ[s0]);
-        Probe P, Q;
-        if (!probe_setup(v, j, P, Q, true)) { EXD(3, st); return 3; }
+        const uint32_t c1 = (ns == 2 && st != EX_ST_I) ? gld(&G.succ[s0 + 1]) : EX_NIL;
         uint32_t kind = 1;
+        if (st != EX_ST_I && (c == G.end_row || c1 == G.end_row)) { EXD(4, st); return 3; }
         if (st == EX_ST_M) {
-            // a Match state goes through the greedy extension: a single successor that is not the end, query not exhausted
-            if (c == G.end_row || j >= L) { EXD(4, st); return 3; }
+            // a Match state goes through the greedy extension
+            if (j >= L) { EXD(4, st); return 3; }
             if (j == 0 && L != 0 && is_symbol_equal(v, seq[0])) { EXD(4, st); return 3; }  // the offset-0 special case, dfa.rs:146-167
-            if (gld(&G.sym[c]) == seq[j]) kind = 2;
+            const uint8_t qc = seq[j];
+            if (gld(&G.sym[c]) == qc) kind = 2;
+            if (c1 != EX_NIL && gld(&G.sym[c1]) == qc) { EXD(1, st); return 3; }   // (a second branch to extend: the generic code keeps the stack)
         }
+        Probe P, Q;
+        const bool probes = probe_setup(v, j, P, Q, true);
         // ---- every load of the step, before any use ----
         const uint32_t i_own = cix(v, j, st);
-        uint32_t i0, i1, i2 = i_own;
-        if (st == EX_ST_M) { i0 = cix(c, j + 1, EX_ST_M); i1 = cix(v, j + 1, EX_ST_I); i2 = cix(c, j, EX_ST_D); }
+        uint32_t i0, i1, i2 = i_own, i3 = i_own, i4 = i_own;
+        if (st == EX_ST_M) { i0 = cix(c, j + 1, EX_ST_M); i1 = cix(v, j + 1, EX_ST_I); i2 = cix(c, j, EX_ST_D); if (c1 != EX_NIL) { i3 = cix(c1, j + 1, EX_ST_M); i4 = cix(c1, j, EX_ST_D); } }
         else if (st == EX_ST_I) { i0 = cix(v, j, EX_ST_M); i1 = cix(v, j < L ? j + 1 : j, EX_ST_I); }
-        else { i0 = cix(v, j, EX_ST_M); i1 = cix(c, j, EX_ST_D); }
+        else { i0 = cix(v, j, EX_ST_M); i1 = cix(c, j, EX_ST_D); if (c1 != EX_NIL) i3 = cix(c1, j, EX_ST_D); }
         uint32_t own = W.T[i_own];
         uint32_t t0 = W.T[i0], t1 = W.T[i1], t2 = st == EX_ST_M ? W.T[i2] : EX_INF;
-        probe_load(P);
-        probe_load(Q);
+        uint32_t t3 = c1 != EX_NIL ? W.T[i3] : EX_INF, t4 = (c1 != EX_NIL && st == EX_ST_M) ? W.T[i4] : EX_INF;
+        if (probes) { probe_load(P); probe_load(Q); }
         if (spec) {
             // (the probes note what they looked at when they decide)
             note_cell(i_own); note_cell(i0); if (st != EX_ST_I || j < L) note_cell(i1); if (st == EX_ST_M) note_cell(i2);
-            if (sl.n_w) { own = ovl(i_own, own); t0 = ovl(i0, t0); t1 = ovl(i1, t1); if (st == EX_ST_M) t2 = ovl(i2, t2); }
+            if (c1 != EX_NIL) { note_cell(i3); if (st == EX_ST_M) note_cell(i4); }
+            if (sl.n_w) {
+                own = ovl(i_own, own); t0 = ovl(i0, t0); t1 = ovl(i1, t1); if (st == EX_ST_M) t2 = ovl(i2, t2);
+                if (c1 != EX_NIL) { t3 = ovl(i3, t3); if (st == EX_ST_M) t4 = ovl(i4, t4); }
+            }
         }
         if (st == EX_ST_I && j >= L) t1 = EX_INF;
         n_fast += 1;
         if (g > own) return 1;                      // stale (astar.rs:146)
-        const uint32_t r = probe_decide2(P, Q, g, st);
-        if (r == 3) { EXD(5, st); return 3; }
+        uint32_t r = probes ? probe_decide2(P, Q, g, st) : 3u;
+        if (r == 3) { PF_TICK(1); r = (C.prune && prune(g, v, j, st)) ? 2u : 0u; PF_TICK(5); }   // bubbles of another shape: the generic test (astar.rs:155)
+        if (err) return 3;
         EXD(r == 0 ? (kind == 2 ? 7 : 6) : 0, st);
-        F.kind = kind; F.c = c; F.t0 = t0; F.t1 = t1; F.t2 = t2;
+        F.kind = kind; F.c = c; F.c1 = c1; F.t0 = t0; F.t1 = t1; F.t2 = t2; F.t3 = t3; F.t4 = t4;
         return r;
     }
     // The expansion of a state inspect_fast let through.  true: the search ends here (only through the generic tail).
@@ -943,7 +992,7 @@ public:
         mark_reached(v, j, st);
         num_visited += 1;
         if (err) return false;
-        const uint32_t c = F.c;
+        const uint32_t c = F.c, c1 = F.c1;
         if (st == EX_ST_I) {
             if (g < F.t0) { wr(v, j, EX_ST_M, g); queue_state(v, j, EX_ST_M, g); }
             const uint32_t ns = g + C.e;
@@ -954,23 +1003,26 @@ public:
             if (g < F.t0) { wr(v, j, EX_ST_M, g); queue_state(v, j, EX_ST_M, g); }
             const uint32_t ns = g + C.e;
             if (ns < F.t1) { wr(c, j, EX_ST_D, ns); queue_state(c, j, EX_ST_D, ns); }
+            if (c1 != EX_NIL && ns < F.t3) { wr(c1, j, EX_ST_D, ns); queue_state(c1, j, EX_ST_D, ns); }
             return false;
         }
+        const uint32_t nm = g + C.x, ng = g + C.o + C.e;
+        bool i_open = false;   // I[v][j+1] relaxed by a mismatch event of this row (a second one cannot lower it again)
         if (F.kind == 1) {
-            // the only successor mismatches -> expand_mismatch (gap_affine.rs:393-430), then the extension has nothing left
-            const uint32_t nm = g + C.x, ng = g + C.o + C.e;
+            // the first successor mismatches -> expand_mismatch (gap_affine.rs:393-430)
             if (nm < F.t0) { wr(c, j + 1, EX_ST_M, nm); queue_state(c, j + 1, EX_ST_M, nm); }
             if (ng < F.t1) { wr(v, j + 1, EX_ST_I, ng); queue_state(v, j + 1, EX_ST_I, ng); }
             if (ng < F.t2) { wr(c, j, EX_ST_D, ng); queue_state(c, j, EX_ST_D, ng); }
-            return false;
-        }
+            i_open = true;
+        } else {
         // Greedy extension along single-successor rows (dfa.rs:138-250).  A parent with one successor has nothing left once
         // that successor is taken, so it need not stay on the stack: the walk keeps only its tip.  One round trip per
         // matched base: the tip's cell, the bubble test of the tip and the cells a mismatch would relax, all loaded together.
+        // (The row the walk starts from may have a second successor: it is looked at when the walk is over, below.)
         uint32_t cj = j, cc = c, tm = F.t0;
         dfa_visited = 0; dfa_score = g;
         for (;;) {
-            // here: cc is the single successor of cv, not the end row, cj < L, sym(cc) == seq[cj]
+            // here: cc is a successor of the row before, not the end row, cj < L, sym(cc) == seq[cj]
             const uint32_t nj = cj + 1;
             if (spec && (sl.flags & SPF_COMPLEX)) break;   // (the lane is cut off: whatever it does from here on is discarded)
             if (!(g < tm)) break;                          // already there with this score or better: not extended (dfa.rs:242)
@@ -1004,15 +1056,23 @@ public:
                 break;
             }
             if (gld(&G.sym[nc]) != seq[nj]) {
-                const uint32_t nm = g + C.x, ng = g + C.o + C.e;
-                if (nm < n0) { wr(nc, nj + 1, EX_ST_M, nm); queue_state(nc, nj + 1, EX_ST_M, nm); }
-                if (ng < n1) { wr(cc, nj + 1, EX_ST_I, ng); queue_state(cc, nj + 1, EX_ST_I, ng); }
-                if (ng < n2) { wr(nc, nj, EX_ST_D, ng); queue_state(nc, nj, EX_ST_D, ng); }
+                const uint32_t xm = g + C.x, xg = g + C.o + C.e;
+                if (xm < n0) { wr(nc, nj + 1, EX_ST_M, xm); queue_state(nc, nj + 1, EX_ST_M, xm); }
+                if (xg < n1) { wr(cc, nj + 1, EX_ST_I, xg); queue_state(cc, nj + 1, EX_ST_I, xg); }
+                if (xg < n2) { wr(nc, nj, EX_ST_D, xg); queue_state(nc, nj, EX_ST_D, xg); }
                 break;
             }
             cj = nj; cc = nc; tm = n0;
         }
         num_visited += dfa_visited;
+        if (err) return false;
+        }
+        if (c1 != EX_NIL) {
+            // the second successor (it mismatches: inspect_fast) -> its mismatch event, after whatever the first one led to
+            if (nm < F.t3) { wr(c1, j + 1, EX_ST_M, nm); queue_state(c1, j + 1, EX_ST_M, nm); }
+            if (!i_open && ng < F.t1) { wr(v, j + 1, EX_ST_I, ng); queue_state(v, j + 1, EX_ST_I, ng); }
+            if (ng < F.t4) { wr(c1, j, EX_ST_D, ng); queue_state(c1, j, EX_ST_D, ng); }
+        }
         return false;
     }
 
@@ -1110,7 +1170,7 @@ public:
             const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
             uint32_t n = nb;
             ExU4 e{0, 0, 0, 0};
-            FastItem F{0, 0, 0, 0, 0};
+            FastItem F{0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t i = 0; i < nb && !err; ++i) {
                 e = ch[d.n_top - i];
                 uint32_t sk = use_fast ? inspect_fast(e.x, e.y, e.z, st, F) : 3u;
@@ -1137,22 +1197,30 @@ public:
     // log.  sl.flags says how it ended; the counters of the search are left untouched (sl.dq / dv / dp carry the deltas).
     POA_HD void spec_group(uint32_t g, uint32_t v, uint32_t j, uint32_t st, uint32_t f, uint32_t rmax, ExactResult& R, uint32_t& end_score,
                            bool use_fast = true) {
-        sl.n_w = sl.n_m = sl.n_p = sl.n_pd = 0; sl.flags = 0; sl.n_rc = sl.n_rm = 0; sl.n_ent = 0;
+        sl.n_w = sl.n_m = sl.n_p = sl.n_pd = 0; sl.flags = 0; sl.n_rc = sl.n_rm = 0; sl.n_ent = 0; sl.wmask = sl.mmask = 0;
+        rc_x = rs_x = EX_NIL;
         sl.cur_f = f; sl.root_st = st;
         const uint32_t q0 = num_queued, v0 = num_visited, p0 = num_pruned;
         spec = true;
         for (;;) {
             // (an entry after the first that does not fit the logs is put back: it and what else is pending go to the queue)
+            PF_START();
             const SpecLane snap = sl;
             const uint32_t q1 = num_queued, v1 = num_visited, p1 = num_pruned;
             if (sl.n_ent) spec_pending_pop(g, v, j, st);
-            FastItem F{0, 0, 0, 0, 0};
+            FastItem F{0, 0, 0, 0, 0, 0, 0, 0};
+            PF_TICK(0);
             uint32_t sk = use_fast ? inspect_fast(g, v, j, st, F) : 3u;
+            PF_TICK(1);
             if (sk == 3 && !err && !(sl.flags & SPF_COMPLEX)) sk = inspect_skip(g, v, j, st);
+            PF_TICK(2);
             bool found = false;
             if (!err && !(sl.flags & SPF_COMPLEX)) {
                 if (sk == 2) num_pruned += 1;
-                if (sk == 0) found = F.kind ? process_fast(g, v, j, st, F, R, end_score) : process_popped(g, v, j, st, R, end_score);
+                if (sk == 0) {
+                    if (F.kind) { found = process_fast(g, v, j, st, F, R, end_score); PF_TICK(3); }
+                    else { found = process_popped(g, v, j, st, R, end_score); PF_TICK(4); }
+                }
             }
             if (err || (sl.flags & SPF_COMPLEX)) {
                 if (sl.n_ent == 0) break;
@@ -1174,7 +1242,7 @@ public:
     POA_HD bool spec_reads_what(const SpecLane& o) const {
         for (uint32_t a = 0; a < sl.n_rc; ++a)
             for (uint32_t b = 0; b < o.n_w; ++b)
-                if (sl.rc[a * sl.stride] == o.w_idx[b * o.stride]) return true;
+                if (sl.rc[a * sl.stride] == sp_hash16(o.w_idx[b * o.stride])) return true;
         for (uint32_t a = 0; a < sl.n_rm; ++a)
             for (uint32_t b = 0; b < o.n_m; ++b)
                 if (sl.rm_x[a * sl.stride] == o.m_x[b * o.stride] && sl.rm_lo[a * sl.stride] <= o.m_off[b * o.stride] && o.m_off[b * o.stride] <= sl.rm_hi[a * sl.stride]) return true;
@@ -1182,8 +1250,8 @@ public:
     }
     // commit of one lane's log: cell writes, marks, counters (queue pushes are the caller's: they need the lanes' order)
     POA_HD void spec_commit(const SpecLane& l) {
-        for (uint32_t k = 0; k < l.n_w; ++k) W.T[l.w_idx[k * l.stride]] = l.w_val[k * l.stride];
-        for (uint32_t k = 0; k < l.n_m; ++k) mark_word(l.m_x[k * l.stride], l.m_off[k * l.stride]);
+        for (uint32_t k = 0; k < l.n_w; ++k) W.T[sld(&l.w_idx[k * l.stride])] = sld(&l.w_val[k * l.stride]);
+        for (uint32_t k = 0; k < l.n_m; ++k) mark_word(sld(&l.m_x[k * l.stride]), sld(&l.m_off[k * l.stride]));
         num_queued += l.dq; num_visited += l.dv; num_pruned += l.dp;
     }
 
@@ -1201,7 +1269,7 @@ public:
         uint32_t end_score = EX_INF;
         bool found = false;
         if (lanes > 63) lanes = 63;
-        struct LaneBuf { uint32_t w_idx[SP_KW], w_val[SP_KW], m_x[SP_KM], m_off[SP_KM], rc[SP_KRC], rm_x[SP_KRM], rm_lo[SP_KRM], rm_hi[SP_KRM]; ExU4 p[SP_KP]; ExStackEntry ds[SP_KDS]; };
+        struct LaneBuf { uint32_t w_idx[SP_KW], w_val[SP_KW], m_x[SP_KM], m_off[SP_KM], rm_x[SP_KRM], rm_lo[SP_KRM], rm_hi[SP_KRM]; uint16_t rc[SP_KRC]; ExU4 p[SP_KP]; ExStackEntry ds[SP_KDS]; };
         LaneBuf* buf = new LaneBuf[64];
         SpecLane* ls = new SpecLane[64];
         ExactResult* rs = new ExactResult[64];
@@ -1227,6 +1295,15 @@ public:
                 bool cut_before = (sl.flags & SPF_COMPLEX) != 0;
                 for (uint32_t a = 0; a < i && !cut_before; ++a) {
                     cut_before = spec_reads_what(ls[a]);
+#if defined(POA_EXACT_DIAG)
+                    if (cut_before && getenv("EXH_CONFLICTS")) {
+                        const ExU4 ea = ch[d.n_top - a];
+                        bool cellhit = false;
+                        for (uint32_t x_ = 0; x_ < sl.n_rc; ++x_) for (uint32_t y_ = 0; y_ < ls[a].n_w; ++y_) if (sl.rc[x_] == sp_hash16(ls[a].w_idx[y_])) cellhit = true;
+                        fprintf(stderr, "conflict st %u lanes %u<-%u  reader (row %u off %u g %u) writer (row %u off %u g %u) %s  writer: %u cells %u marks %u entries\n", st, i, a, e.y, e.z, e.x, ea.y, ea.z, ea.x,
+                                cellhit ? "CELL" : "MARK", ls[a].n_w, ls[a].n_m, ls[a].n_ent);
+                    }
+#endif
                 }
                 if (cut_before) { seq0 = i == 0; if (i) { if (sl.flags & SPF_COMPLEX) par_cut_complex += 1; else { par_cut_conflict += 1; par_hist_conf[i] += 1; } } break; }
                 n_commit = i + 1; par_entries += sl.n_ent;

@@ -27,7 +27,8 @@
 
 namespace poa_amd {
 
-constexpr uint32_t PS_TAB = 512;   // slots of the conflict table (lane masks), per wave
+constexpr uint32_t PS_TAB = 512;       // slots of each of the two conflict tables (lowest writing lane per key), per wave
+constexpr uint32_t PS_TAB_BITS = 9;
 
 struct PSearchParams {
     ExactParams E;            // graph, queries, planes, reached sets, costs, status / end cell
@@ -37,31 +38,42 @@ struct PSearchParams {
     uint32_t* ring_global;    // null: the rings live in LDS; else [slots * 3 * win] in global memory
     uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
     uint32_t waves_per_block;
-    uint32_t max_lanes;       // entries per step (<= 63)
+    uint32_t group;           // lanes per query: 64 (one query per wave), 32 or 16
+    uint32_t max_lanes;       // entries per step (<= group - 1)
     uint32_t rmax;            // entries a lane may process per step (its own and what they push in front of the next)
-    uint32_t* scratch;        // per slot: ps_scratch_words() words — the lanes' logs
+    uint32_t* scratch;        // per slot: ps_scratch_words() words — the lanes' push logs and extension stacks
     uint32_t* work_counter;   // persistent scheduling (see poa_wsearch.hpp); null: query = block / wave index
     const uint32_t* order;
     uint32_t* counters;       // optional [4 * total]: num_queued, num_visited, num_pruned, steps
     unsigned long long* prof; // optional [8 * total]: cycles per phase
 };
 
-// per wave, in words: cell-write log (index, value), marks (exit, offset), pushes (4 words), extension stack (3 words)
-__host__ __device__ inline uint32_t ps_scratch_words() { return 64u * (2 * SP_KW + 2 * SP_KM + 4 * SP_KP + 3 * SP_KDS); }
-// per wave, in bytes of LDS: conflict table, read cells, mark ranges (exit, lo, hi), their counts, one word for the lanes found in conflict
-__host__ __device__ inline uint32_t ps_lds_bytes() { return 8u * PS_TAB + 4u * 64u * (SP_KRC + 3 * SP_KRM + 1) + 16u; }
+// per wave, in words of global memory: pushes (4 words each), extension stack (3 words)
+__host__ __device__ inline uint32_t ps_scratch_words() { return 64u * (4 * SP_KP + 3 * SP_KDS); }
+// per wave, in bytes of LDS: two conflict tables | cell-write log (index, value) | marks (exit, offset) | mark ranges read (exit, lo, hi) |
+// read cells (16-bit hashes) | counts | sequence -> (lane, slot) map of the step's pushes | the lanes found in conflict
+constexpr uint32_t PS_O_W = 2u * 4u * PS_TAB;
+constexpr uint32_t PS_O_M = PS_O_W + 4u * 64u * 2 * SP_KW;
+constexpr uint32_t PS_O_RM = PS_O_M + 4u * 64u * 2 * SP_KM;
+constexpr uint32_t PS_O_RC = PS_O_RM + 4u * 64u * 3 * SP_KRM;
+constexpr uint32_t PS_O_CNT = PS_O_RC + 2u * 64u * SP_KRC;
+constexpr uint32_t PS_O_MAP = PS_O_CNT + 4u * 64u;
+constexpr uint32_t PS_O_CONF = PS_O_MAP + 2u * 64u * SP_KP;
+__host__ __device__ inline uint32_t ps_lds_bytes() { return PS_O_CONF + 16u; }
 
 __device__ __forceinline__ uint32_t ps_bcast(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 __device__ __forceinline__ uint32_t ps_wave_sum(uint32_t v) {
     for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
     return v;
 }
-__device__ __forceinline__ uint32_t ps_key_cell(uint32_t ix) { return ((ix >> 6) * 0x9E3779B1u) >> (32 - 9); }          // PS_TAB == 512
-__device__ __forceinline__ uint32_t ps_key_mark(uint32_t x, uint32_t word) { return ((x * 0x85EBCA6Bu + word * 0xC2B2AE35u + 0x27D4EB2Fu) * 0x9E3779B1u) >> (32 - 9); }
+// two independent table slots per key (second table behind the first): a cell by the 16-bit hash of its index, a word of a reached set
+__device__ __forceinline__ uint32_t ps_key1(uint32_t k) { return (k * 0x9E3779B1u) >> (32 - PS_TAB_BITS); }
+__device__ __forceinline__ uint32_t ps_key2(uint32_t k) { return PS_TAB + ((k * 0x85EBCA6Bu + 0x165667B1u) >> (32 - PS_TAB_BITS)); }
+__device__ __forceinline__ uint32_t ps_mark_id(uint32_t x, uint32_t word) { return 0x80000000u | (x * 0x3D4D51CBu + word * 0xC2B2AE35u); }
 constexpr uint32_t PS_ALL_WORDS = 0xFFFFFFu;   // "some word of this exit's set": key of a range too wide to name its words
 
-template <int AS>
-__device__ __forceinline__ void ps_search_query(const PSearchParams& P, const ExactGraph& G, uint32_t* ring, uint8_t* wlds, uint32_t lane, uint32_t wave);
+template <int AS, int GS>
+__device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGraph& G, uint8_t* wbase, uint32_t lane, uint32_t wave);
 
 __global__ __launch_bounds__(512) void poa_psearch_kernel(PSearchParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -89,63 +101,58 @@ __global__ __launch_bounds__(512) void poa_psearch_kernel(PSearchParams P) {
         G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(E.G.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)E.n_nbm));
     }
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // per wave: [descriptor ring (unless global)] [conflict table | read cells | mark ranges | conflict word]
-    const uint32_t ring_bytes = P.ring_global ? 0u : 3u * P.win * 4u;
-    const uint32_t per_wave = ((ring_bytes + 15u) & ~15u) + ps_lds_bytes();
-    uint8_t* wbase = lds + P.graph_lds + (uint64_t)wave * per_wave;
-    uint32_t* ring = P.ring_global ? nullptr : reinterpret_cast<uint32_t*>(wbase);
-    uint8_t* wlds = wbase + ((ring_bytes + 15u) & ~15u);
-    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;
-    if (P.ring_global) ring = P.ring_global + (uint64_t)slot * 3 * P.win;
-    for (uint32_t i = lane; i < 3 * P.win; i += 64) ring[i] = BQ_EMPTY;
+    // per wave: [descriptor rings of its queries (unless global)] [conflict tables | logs | read sets | push map]
+    const uint32_t qpw = 64u / P.group;
+    const uint32_t ring_bytes = P.ring_global ? 0u : ((qpw * 3u * P.win * 4u + 15u) & ~15u);
+    uint8_t* wbase = lds + P.graph_lds + (uint64_t)wave * (ring_bytes + ps_lds_bytes());
     __syncthreads();
+    // graph arrays and rings both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers for those two
     const bool lds_all = P.graph_lds && !P.ring_global;
-    if (lds_all) ps_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS>(P, G, ring, wlds, lane, wave);
-    else ps_search_query<0>(P, G, ring, wlds, lane, wave);
+    if (P.group == 64) {
+        if (lds_all) ps_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, 64>(P, G, wbase, lane, wave);
+        else ps_search<EX_AS_READSET_LDS, 64>(P, G, wbase, lane, wave);
+    } else if (P.group == 32) {
+        if (lds_all) ps_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, 32>(P, G, wbase, lane, wave);
+        else ps_search<EX_AS_READSET_LDS, 32>(P, G, wbase, lane, wave);
+    } else {
+        if (lds_all) ps_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, 16>(P, G, wbase, lane, wave);
+        else ps_search<EX_AS_READSET_LDS, 16>(P, G, wbase, lane, wave);
+    }
 }
 
-template <int AS>
-__device__ __forceinline__ void ps_search_query(const PSearchParams& P, const ExactGraph& G, uint32_t* ring, uint8_t* wlds, uint32_t lane, uint32_t wave) {
+// GS lanes per query, 64 / GS queries per wave, all stepping through one instruction stream: what is uniform over a wave with one
+// query (queue state, the cut of a step) is uniform over a group here and travels by shuffles inside the group.
+template <int AS, int GS>
+__device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGraph& G, uint8_t* wbase, uint32_t lane, uint32_t wave) {
     const ExactParams& E = P.E;
-    const uint32_t slot = blockIdx.x * P.waves_per_block + wave;   // this wave's workspace (reached sets, chunks, ring, logs)
+    constexpr uint32_t QPW = 64u / GS;
+    const uint32_t grp = lane / GS, gl = lane % GS, gbase = grp * GS;
+    constexpr unsigned long long GM = GS == 64 ? ~0ull : ((1ull << (GS & 63)) - 1);
+    const uint32_t slot = (blockIdx.x * P.waves_per_block + wave) * QPW + grp;   // this group's workspace (reached sets, chunks, ring)
+    const uint32_t wslot = blockIdx.x * P.waves_per_block + wave;               // the wave's (push logs)
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    lds_u64* tab = (lds_u64*)wlds;
-    uint32_t* l_rc = reinterpret_cast<uint32_t*>(wlds + 8u * PS_TAB);
-    uint32_t* l_rm = l_rc + 64u * SP_KRC;
-    lds_u32* l_cnt = (lds_u32*)(l_rm + 64u * 3 * SP_KRM);   // n_rc | n_rm << 16 of every lane
-    lds_u64* l_conf = (lds_u64*)(wlds + 8u * PS_TAB + 4u * 64u * (SP_KRC + 3 * SP_KRM + 1));
-    uint32_t* sc = P.scratch + (uint64_t)slot * ps_scratch_words();
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    const uint32_t ring_bytes = P.ring_global ? 0u : ((QPW * 3u * P.win * 4u + 15u) & ~15u);
+    uint32_t* ring = P.ring_global ? P.ring_global + (uint64_t)slot * 3 * P.win : reinterpret_cast<uint32_t*>(wbase) + (uint64_t)grp * 3 * P.win;
+    uint8_t* wlds = wbase + ring_bytes;
+    lds_u32* tab = (lds_u32*)wlds;   // [PS_TAB | PS_TAB]
+    uint32_t* l_w = reinterpret_cast<uint32_t*>(wlds + PS_O_W);      // [w_idx: SP_KW x 64][w_val: SP_KW x 64]
+    uint32_t* l_m = reinterpret_cast<uint32_t*>(wlds + PS_O_M);      // [m_x][m_off]
+    uint32_t* l_rm = reinterpret_cast<uint32_t*>(wlds + PS_O_RM);    // [rm_x][rm_lo][rm_hi]
+    uint16_t* l_rc = reinterpret_cast<uint16_t*>(wlds + PS_O_RC);
+    lds_u16* l_map = (lds_u16*)(wlds + PS_O_MAP) + gbase * SP_KP;    // this group's part: GS * SP_KP entries
+    uint32_t* sc = P.scratch + (uint64_t)wslot * ps_scratch_words();
     const unsigned long long lanebit = 1ull << lane;
-    const unsigned long long above = lane == 63 ? 0ull : (~0ull << (lane + 1));
-    bool first = true;
-    for (;;) {
-    uint32_t pos = slot;
-    if (P.work_counter) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(P.work_counter, 1u);
-        pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (pos >= E.n_queries) return;
-        if (P.order) pos = P.order[pos];
-    } else if (!first) return;
-    else if (slot >= E.n_queries) return;
-    const uint32_t qi = E.first_query + pos;
-    if (E.hybrid && E.dense_flags[qi] == 0) { first = false; continue; }
-    if (!first || P.work_counter) {
-        // the workspace of the previous search of this wave: reached sets back to empty, ring back to empty
-        uint64_t* z = E.reached + (uint64_t)slot * E.G.n_exit * E.wpn;
-        for (uint64_t i = lane; i < (uint64_t)E.G.n_exit * E.wpn; i += 64) z[i] = 0;
-        uint64_t* zs = E.rsum + (uint64_t)slot * E.G.n_exit * E.swpn;
-        for (uint64_t i = lane; i < (uint64_t)E.G.n_exit * E.swpn; i += 64) zs[i] = 0;
-        for (uint32_t i = lane; i < 3 * P.win; i += 64) ring[i] = BQ_EMPTY;
-    }
-    first = false;
-    const uint64_t qbeg = E.qoff[qi];
-    const uint32_t L = (uint32_t)(E.qoff[qi + 1] - qbeg);
+    const uint32_t gsalt = grp * 0x632BE5ABu;   // keeps the groups apart in the shared conflict tables
+    auto gsh = [&](uint32_t v, uint32_t src_gl) { return (uint32_t)__shfl((int)v, (int)(gbase + src_gl), 64); };
+    auto gballot = [&](bool p) { return (__ballot(p) >> gbase) & GM; };
+
+    // workspace of the group: constant over its queries but for the planes
     ExactWork W;
-    W.T = E.planes + E.plane_off[qi];
+    W.T = E.planes;
     W.n_rows = E.G.n_rows;
-    W.pitch = E.pitch[qi];
+    W.pitch = 64;
     W.reached = E.reached + (uint64_t)slot * E.G.n_exit * E.wpn;
     W.rsum = E.rsum + (uint64_t)slot * E.G.n_exit * E.swpn;
     W.wpn = E.wpn; W.swpn = E.swpn;
@@ -156,53 +163,99 @@ __device__ __forceinline__ void ps_search_query(const PSearchParams& P, const Ex
     W.bq_desc = ring; W.bq_win = P.win;
     W.bq_chunks = P.chunks + (uint64_t)slot * P.chunk_cap * BQ_CHUNK;
     W.bq_chunk_cap = P.chunk_cap;
-
-    ExactSearchT<AS> S(G, W, E.qseq + qbeg, L, E.C);
+    ExactSearchT<AS> S(G, W, E.qseq, 0, E.C);
     // the lane's logs (element k at base[k * 64])
     S.sl.stride = 64;
-    S.sl.w_idx = sc + lane; S.sl.w_val = sc + 64u * SP_KW + lane;
-    S.sl.m_x = sc + 64u * 2 * SP_KW + lane; S.sl.m_off = sc + 64u * (2 * SP_KW + SP_KM) + lane;
-    S.sl.p = reinterpret_cast<ExU4*>(sc + 64u * (2 * SP_KW + 2 * SP_KM)) + lane;
-    S.sl.dstack = reinterpret_cast<ExStackEntry*>(sc + 64u * (2 * SP_KW + 2 * SP_KM + 4 * SP_KP)) + lane;
-    S.sl.rc = l_rc + lane; S.sl.rm_x = l_rm + lane; S.sl.rm_lo = l_rm + 64u * SP_KRM + lane; S.sl.rm_hi = l_rm + 64u * 2 * SP_KRM + lane;
-    ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
-    uint32_t end_score = EX_INF, found = 0, steps = 0;
+    S.sl.w_idx = l_w + lane; S.sl.w_val = l_w + 64u * SP_KW + lane;
+    S.sl.m_x = l_m + lane; S.sl.m_off = l_m + 64u * SP_KM + lane;
+    S.sl.rm_x = l_rm + lane; S.sl.rm_lo = l_rm + 64u * SP_KRM + lane; S.sl.rm_hi = l_rm + 64u * 2 * SP_KRM + lane;
+    S.sl.rc = l_rc + lane;
+    S.sl.p = reinterpret_cast<ExU4*>(sc) + lane;
+    S.sl.dstack = reinterpret_cast<ExStackEntry*>(sc + 64u * 4 * SP_KP) + lane;
+    ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, 0};
+    uint32_t end_score = EX_INF, found = 0, steps = 0, qi = 0;
+    bool have = false, more = slot < E.n_queries, first = true;   // (the workspace has a slot per query of the chunk at least)
 
-    // uniform state lives identically in every lane; whatever one lane changes alone is broadcast afterwards
+    // group-uniform state lives identically in every lane of the group; what one lane changes alone is handed round afterwards
     auto adopt = [&](uint32_t from) {
-        S.err = ps_bcast(S.err, from);
-        S.layer_min = ps_bcast(S.layer_min, from);
-        S.bq_live = ps_bcast(S.bq_live, from);
-        S.bq_hi = ps_bcast(S.bq_hi, from);
-        S.bq_chunk_top = ps_bcast(S.bq_chunk_top, from);
-        S.bq_free = ps_bcast(S.bq_free, from);
-        found = ps_bcast(found, from);
-        end_score = ps_bcast(end_score, from);
-        R.end_row = ps_bcast(R.end_row, from);
-        R.end_off = ps_bcast(R.end_off, from);
+        S.err = gsh(S.err, from);
+        S.layer_min = gsh(S.layer_min, from);
+        S.bq_live = gsh(S.bq_live, from);
+        S.bq_hi = gsh(S.bq_hi, from);
+        S.bq_chunk_top = gsh(S.bq_chunk_top, from);
+        S.bq_free = gsh(S.bq_free, from);
+        found = gsh(found, from);
+        end_score = gsh(end_score, from);
+        R.end_row = gsh(R.end_row, from);
+        R.end_off = gsh(R.end_off, from);
     };
-    if (lane == 0) S.push_initial_states();
-    adopt(0);
-    S.bq_wr = lane == 0;
 
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool prof = P.prof != nullptr;
 #define PS_TICK(k) do { if (prof) { const unsigned long long now_ = clock64(); pc[k] += now_ - t_last; t_last = now_; } } while (0)
     unsigned long long t_last = prof ? clock64() : 0;
-    while (!found && !S.err) {
-        uint32_t st; BqDesc d;
-        if (!S.bq_current(st, d)) { S.err = EX_PANIC; break; }   // "Could not align sequence!" (astar.rs:142-144)
+    for (;;) {
+        // ---- groups without a search take the next query (persistent scheduling: longest expected search first) ----
+        if (__any(!have && more)) {
+            uint32_t t = EX_NIL;
+            if (!have && more && gl == 0) {
+                if (P.work_counter) t = atomicAdd(P.work_counter, 1u);
+                else if (first && slot < E.n_queries) t = slot;
+            }
+            const bool want = !have && more;
+            t = gsh(t, 0);
+            first = false;
+            if (want) {
+                if (t >= E.n_queries) more = false;
+                else {
+                    const uint32_t pos = P.order ? P.order[t] : t;
+                    qi = E.first_query + pos;
+                    if (!(E.hybrid && E.dense_flags[qi] == 0)) {
+                        // the group's workspace: reached sets back to empty, ring back to empty (the host clears nothing)
+                        uint64_t* z = W.reached;
+                        for (uint64_t i = gl; i < (uint64_t)E.G.n_exit * E.wpn; i += GS) z[i] = 0;
+                        uint64_t* zs = W.rsum;
+                        for (uint64_t i = gl; i < (uint64_t)E.G.n_exit * E.swpn; i += GS) zs[i] = 0;
+                        for (uint32_t i = gl; i < 3 * P.win; i += GS) ring[i] = BQ_EMPTY;
+                        const uint64_t qbeg = E.qoff[qi];
+                        W.T = E.planes + E.plane_off[qi];
+                        W.pitch = E.pitch[qi];
+                        S.begin_query(E.qseq + qbeg, (uint32_t)(E.qoff[qi + 1] - qbeg));
+                        R = ExactResult{EX_OK, EX_INF, 0, 0, 0, G.end_row, S.L};
+                        end_score = EX_INF; found = 0; steps = 0;
+                        have = true;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        S.bq_wr = true;
+                        if (gl == 0) S.push_initial_states();
+                    }
+                }
+            }
+            adopt(0);   // (of the lanes that did not take a query: their own lane 0's values — nothing changes)
+            S.bq_wr = gl == 0;
+            if (__any(!have && more)) continue;   // (a group skipped a query the dense pass certified: it asks again)
+        }
+        if (!__any(have)) break;
+
+        // ---- one step of every group that has a search ----
+        const bool go = have && !found && !S.err;
+        uint32_t st = 0; BqDesc d{0, 0};
+        if (go && !S.bq_current(st, d)) S.err = EX_PANIC;   // "Could not align sequence!" (astar.rs:142-144)
+        const bool run = go && !S.err;
         const uint32_t f = S.layer_min;
-        const uint32_t nb = d.n_top < P.max_lanes ? d.n_top : P.max_lanes;   // <= 63 entries in the top chunk: lane i takes the i-th from the top
+        const uint32_t cap = P.max_lanes < (uint32_t)(GS - 1) ? P.max_lanes : (uint32_t)(GS - 1);
+        const uint32_t nb = run ? (d.n_top < cap ? d.n_top : cap) : 0u;   // the top chunk's entries: lane i of the group takes the i-th from the top
         const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
-        const bool act = lane < nb;
-        const ExU4 e = ch[act ? d.n_top - lane : 0];   // the idle lanes read slot 0: {previous chunk}
-        const uint32_t prev = ps_bcast(e.x, 63);         // lane 63 is never active (nb <= 63)
-        // the conflict table of this step
-        tab[lane] = 0; tab[lane + 64] = 0; tab[lane + 128] = 0; tab[lane + 192] = 0;
-        tab[lane + 256] = 0; tab[lane + 320] = 0; tab[lane + 384] = 0; tab[lane + 448] = 0;
-        if (lane == 0) *l_conf = 0;
-        steps += 1;
+        const bool act = gl < nb;
+        ExU4 e{0, 0, 0, 0};
+        if (run) e = ch[act ? d.n_top - gl : 0];             // the idle lanes read slot 0: {previous chunk}
+        const uint32_t prev = gsh(e.x, GS - 1);               // (the last lane of a group is never active)
+        // the conflict tables of this step (4 KB: 8 bytes per lane, eight times)
+        {
+            lds_u64* t8 = (lds_u64*)wlds;
+#pragma unroll
+            for (uint32_t k = 0; k < 2 * PS_TAB / 128; ++k) t8[lane + 64 * k] = ~0ull;
+        }
+        if (run) steps += 1;
         PS_TICK(0);
         // ---- every lane: its entry (and what that puts in front of the next one) in log mode ----
         ExactResult Rl = R; uint32_t esl = end_score;
@@ -210,123 +263,181 @@ __device__ __forceinline__ void ps_search_query(const PSearchParams& P, const Ex
         if (act) S.spec_group(e.x, e.y, e.z, st, f, P.rmax, Rl, esl);
         PS_TICK(1);
         // ---- who read what an earlier lane wrote ----
-        // readers enter their lane under the 64-cell block of every cell / the word of every mark range they depended on ...
-        l_cnt[lane] = S.sl.n_rc | S.sl.n_rm << 16;
+        // Writers enter their lane (lowest wins) under two independent hashes of every cell they logged / every word of a
+        // reached set they marked (and under "some word of that set", for readers of wide ranges); a reader that finds a lower
+        // lane under BOTH hashes of something it depended on is taken to conflict.  A chance match ends the step early, nothing
+        // else: the lanes before the first such reader commit.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (uint32_t k = 0; k < S.sl.n_rc; ++k) __hip_atomic_fetch_or(&tab[ps_key_cell(((lds_u32*)S.sl.rc)[k * 64])], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        for (uint32_t k = 0; k < S.sl.n_rm; ++k) {
-            const uint32_t x = ((lds_u32*)S.sl.rm_x)[k * 64], lo = ((lds_u32*)S.sl.rm_lo)[k * 64], hi = ((lds_u32*)S.sl.rm_hi)[k * 64];
-            const uint32_t w0 = lo >> 6, w1 = hi >> 6;
-            if (w1 - w0 < 3) for (uint32_t w = w0; w <= w1; ++w) __hip_atomic_fetch_or(&tab[ps_key_mark(x, w)], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            else __hip_atomic_fetch_or(&tab[ps_key_mark(x, PS_ALL_WORDS)], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // ... writers look their writes up and check the lanes above them they find there, exactly
-        unsigned long long hit = 0;
         for (uint32_t k = 0; k < S.sl.n_w; ++k) {
-            const uint32_t ix = S.sl.w_idx[k * 64];
-            unsigned long long m = tab[ps_key_cell(ix)] & above;
-            while (m) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t nrc = l_cnt[b] & 0xFFFFu;   // (a shuffle would read an inactive lane here)
-                bool h = false;
-                for (uint32_t r = 0; r < nrc; ++r) h = h || ((lds_u32*)l_rc)[r * 64 + b] == ix;
-                if (h) hit |= 1ull << b;
-            }
+            const uint32_t h16 = ExactSearchT<AS>::sp_hash16(((lds_u32*)l_w)[k * 64 + lane]) ^ gsalt;
+            __hip_atomic_fetch_min(&tab[ps_key1(h16)], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_min(&tab[ps_key2(h16)], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         for (uint32_t k = 0; k < S.sl.n_m; ++k) {
-            const uint32_t x = S.sl.m_x[k * 64], off = S.sl.m_off[k * 64];
-            unsigned long long m = (tab[ps_key_mark(x, off >> 6)] | tab[ps_key_mark(x, PS_ALL_WORDS)]) & above;
-            while (m) {
-                const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t nrm = l_cnt[b] >> 16;
-                bool h = false;
-                for (uint32_t r = 0; r < nrm; ++r)
-                    h = h || (((lds_u32*)l_rm)[r * 64 + b] == x && ((lds_u32*)l_rm)[64 * SP_KRM + r * 64 + b] <= off && off <= ((lds_u32*)l_rm)[128 * SP_KRM + r * 64 + b]);
-                if (h) hit |= 1ull << b;
+            const uint32_t x = ((lds_u32*)l_m)[k * 64 + lane], off = ((lds_u32*)l_m)[64 * SP_KM + k * 64 + lane];
+            const uint32_t ka = ps_mark_id(x, off >> 6) ^ gsalt, kb = ps_mark_id(x, PS_ALL_WORDS) ^ gsalt;
+            __hip_atomic_fetch_min(&tab[ps_key1(ka)], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_min(&tab[ps_key2(ka)], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_min(&tab[ps_key1(kb)], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_min(&tab[ps_key2(kb)], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        bool clash = false;
+        for (uint32_t k0 = 0; k0 < S.sl.n_rc; k0 += 4) {   // (four at a time: eight table reads in flight)
+            uint32_t hh[4], ta[4], tb[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) hh[u] = ((lds_u16*)l_rc)[(k0 + u < SP_KRC ? k0 + u : SP_KRC - 1) * 64 + lane] ^ gsalt;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { ta[u] = tab[ps_key1(hh[u])]; tb[u] = tab[ps_key2(hh[u])]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) clash = clash || (k0 + u < S.sl.n_rc && ta[u] < lane && tb[u] < lane);
+        }
+        for (uint32_t k = 0; k < S.sl.n_rm; ++k) {
+            const uint32_t x = ((lds_u32*)l_rm)[k * 64 + lane], lo = ((lds_u32*)l_rm)[64 * SP_KRM + k * 64 + lane], hi = ((lds_u32*)l_rm)[128 * SP_KRM + k * 64 + lane];
+            const uint32_t w0 = lo >> 6, w1 = hi >> 6;
+            if (w1 - w0 < 3) {
+                for (uint32_t w = w0; w <= w1; ++w) { const uint32_t ka = ps_mark_id(x, w) ^ gsalt; clash = clash || (tab[ps_key1(ka)] < lane && tab[ps_key2(ka)] < lane); }
+            } else {
+                const uint32_t kb = ps_mark_id(x, PS_ALL_WORDS) ^ gsalt;
+                clash = clash || (tab[ps_key1(kb)] < lane && tab[ps_key2(kb)] < lane);
             }
         }
-        if (hit) __hip_atomic_fetch_or(l_conf, hit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const unsigned long long conflict = *l_conf;
         PS_TICK(2);
-        // ---- how many lanes commit ----
-        const unsigned long long active = nb >= 64 ? ~0ull : ((1ull << nb) - 1);
-        const unsigned long long m_cx = __ballot(act && (S.sl.flags & SPF_COMPLEX)) | (conflict & active);
-        const unsigned long long m_last = __ballot(act && (S.sl.flags & (SPF_FOUND | SPF_LEFTOVER)));
+        // ---- how many lanes of the group commit ----
+        const unsigned long long m_cx = gballot(act && (clash || (S.sl.flags & SPF_COMPLEX)));
+        const unsigned long long m_last = gballot(act && (S.sl.flags & (SPF_FOUND | SPF_LEFTOVER)));
         uint32_t n_commit = m_cx ? (uint32_t)__builtin_ctzll(m_cx) : nb;
         if (m_last) { const uint32_t a = (uint32_t)__builtin_ctzll(m_last) + 1; n_commit = a < n_commit ? a : n_commit; }
-        if (n_commit == 0) {
-            // the first lane needs the sequential code (direct mode): its entry alone
-            S.bq_drop(st, d, 1, prev);
-            if (lane == 0) {
-                S.bq_wr = true;
-                const uint32_t sk = S.inspect_skip(e.x, e.y, e.z, st);
-                if (sk == 2) S.num_pruned += 1;
-                if (sk == 0 && !S.err) found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
-                S.bq_wr = false;
+        const bool seq = run && n_commit == 0;   // the group's first lane needs the sequential code (direct mode): its entry alone
+        if (__any(seq)) {
+            if (seq) {
+                S.bq_drop(st, d, 1, prev);
+                if (gl == 0) {
+                    S.bq_wr = true;
+                    const uint32_t sk = S.inspect_skip(e.x, e.y, e.z, st);
+                    if (sk == 2) S.num_pruned += 1;
+                    if (sk == 0 && !S.err) found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+                }
             }
-            S.bq_wr = lane == 0;
+            S.bq_wr = gl == 0;
             adopt(0);
             PS_TICK(4);
-            if (prof) pc[6] += 1;
-            continue;
+            if (prof && seq) pc[6] += 1;
         }
+        const bool com = run && n_commit != 0;
         // ---- commit: table, marks, counters of the lanes before the cut; their entries leave the stack ----
-        if (lane < n_commit) S.spec_commit(S.sl);
-        S.bq_drop(st, d, n_commit, prev);
+        if (com && gl < n_commit) S.spec_commit(S.sl);
+        if (com) S.bq_drop(st, d, n_commit, prev);
         // what the last lane left pending goes on the queue in its push order
-        const uint32_t last = n_commit - 1;
-        const uint32_t npd = ps_bcast(S.sl.n_pd, last);
-        if (npd) {
-            if (lane == last) {
+        const uint32_t last = com ? n_commit - 1 : 0u;
+        const uint32_t npd = gsh(S.sl.n_pd, last);
+        if (__any(com && npd != 0)) {
+            if (com && npd && gl == last) {
                 S.bq_wr = true;
                 if (S.sl.n_pd > 0) S.bq_push(S.sl.pd_key[0] >> 2, S.sl.pd_key[0] & 3u, S.sl.pd_score[0], S.sl.pd_row[0], S.sl.pd_off[0]);
                 if (S.sl.n_pd > 1) S.bq_push(S.sl.pd_key[1] >> 2, S.sl.pd_key[1] & 3u, S.sl.pd_score[1], S.sl.pd_row[1], S.sl.pd_off[1]);
                 if (S.sl.n_pd > 2) S.bq_push(S.sl.pd_key[2] >> 2, S.sl.pd_key[2] & 3u, S.sl.pd_score[2], S.sl.pd_row[2], S.sl.pd_off[2]);
                 if (S.sl.n_pd > 3) S.bq_push(S.sl.pd_key[3] >> 2, S.sl.pd_key[3] & 3u, S.sl.pd_score[3], S.sl.pd_row[3], S.sl.pd_off[3]);
             }
-            S.bq_wr = lane == 0;
-            adopt(last);
+            S.bq_wr = gl == 0;
+            adopt((com && npd) ? last : 0u);
         }
         PS_TICK(3);
-        // the logged pushes, lane after lane (every lane runs the queue code alike; lane 0 stores)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t a = 0; a < n_commit; ++a) {
-            const uint32_t np = ps_bcast(S.sl.n_p, a);
-            const ExU4* pa = reinterpret_cast<const ExU4*>(sc + 64u * (2 * SP_KW + 2 * SP_KM)) + a;
-            for (uint32_t k = 0; k < np; ++k) {
-                const ExU4 q = pa[k * 64];
-                const uint32_t qx = ps_bcast(q.x, 0), qy = ps_bcast(q.y, 0), qz = ps_bcast(q.z, 0), qw = ps_bcast(q.w, 0);
-                S.bq_push(qw >> 2, qw & 3u, qx, qy, qz);
+        // ---- the logged pushes, in the order the sequential loop makes them: lane after lane, each lane's in its own order ----
+        {
+            const uint32_t np_l = (com && gl < n_commit) ? S.sl.n_p : 0u;
+            uint32_t incl = np_l;
+#pragma unroll
+            for (int dd = 1; dd < GS; dd <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, dd, 64); if ((int)gl >= dd) incl += t; }
+            const uint32_t seq0 = incl - np_l, N = gsh(incl, GS - 1);
+            for (uint32_t k = 0; k < np_l; ++k) l_map[seq0 + k] = (uint16_t)(lane | k << 8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const ExU4* plog = reinterpret_cast<const ExU4*>(sc);
+            for (uint32_t base = 0; __any(base < N); base += GS) {
+                const uint32_t i = base + gl;
+                bool pend = i < N;
+                const uint32_t mk = pend ? (uint32_t)l_map[i] : 0u;
+                const ExU4 q = plog[(mk >> 8) * 64 + (mk & 63u)];   // (the idle lanes read the first slot of lane 0)
+                unsigned long long pm = gballot(pend);
+                while (__any(pm != 0 && !S.err)) {
+                    const bool on = pm != 0 && !S.err;
+                    // all entries of the group for one stack, in sequence order
+                    const uint32_t key = gsh(q.w, on ? (uint32_t)__builtin_ctzll(pm) : 0u);
+                    const bool mine = on && pend && q.w == key;
+                    const unsigned long long mm = gballot(mine);
+                    if (on) {
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(mm);
+                    const uint32_t rank = (uint32_t)__builtin_popcountll(mm & ((1ull << gl) - 1));
+                    const uint32_t prio = key >> 2, pst = key & 3u;
+                    // queue.rs:31-54: the layers the queue spans (here: the ring's window)
+                    bool ok = true;
+                    if (S.bq_live == 0) { S.layer_min = prio; S.bq_hi = prio; }
+                    else {
+                        const uint32_t lo = prio < S.layer_min ? prio : S.layer_min, hi = prio > S.bq_hi ? prio : S.bq_hi;
+                        if (hi - lo >= W.bq_win) { S.err = EX_POOL_FULL; ok = false; }
+                        else { S.layer_min = lo; S.bq_hi = hi; }
+                    }
+                    if (ok) {
+                        uint32_t* dp = &W.bq_desc[3 * (prio & (W.bq_win - 1)) + pst];
+                        const uint32_t dw = S.rld(dp);
+                        uint32_t top = dw == BQ_EMPTY ? EX_NIL : dw >> 6, n = dw == BQ_EMPTY ? 0u : dw & 63u;
+                        uint32_t done = 0;
+                        while (done < cnt) {
+                            if (top == EX_NIL || n == BQ_CHUNK - 1) {
+                                const uint32_t c = S.bq_alloc();
+                                if (c == EX_NIL) break;
+                                if (gl == 0) W.bq_chunks[(uint64_t)BQ_CHUNK * c] = ExU4{top, 0, 0, 0};
+                                top = c; n = 0;
+                            }
+                            const uint32_t room = BQ_CHUNK - 1 - n, take = cnt - done < room ? cnt - done : room;
+                            if (mine && rank >= done && rank < done + take) W.bq_chunks[(uint64_t)BQ_CHUNK * top + n + 1 + (rank - done)] = ExU4{q.x, q.y, q.z, 0};
+                            n += take; done += take;
+                        }
+                        if (!S.err) {
+                            if (gl == 0) S.rst(dp, top << 6 | n);
+                            S.bq_live += cnt;
+                        }
+                    }
+                    pend = pend && !mine;
+                    pm &= ~mm;
+                    }
+                }
             }
         }
-        if (m_last && (uint32_t)__builtin_ctzll(m_last) == last) {
-            const uint32_t fl = ps_bcast(S.sl.flags, last);
-            if (fl & SPF_FOUND) {
-                found = 1;
-                end_score = ps_bcast(esl, last);
-                R.end_row = ps_bcast(Rl.end_row, last);
-                R.end_off = ps_bcast(Rl.end_off, last);
-            }
+        {
+            const uint32_t fl = gsh(S.sl.flags, last);
+            const uint32_t es2 = gsh(esl, last), er = gsh(Rl.end_row, last), eo = gsh(Rl.end_off, last);
+            if (com && m_last && (uint32_t)__builtin_ctzll(m_last) == last && (fl & SPF_FOUND)) { found = 1; end_score = es2; R.end_row = er; R.end_off = eo; }
         }
         PS_TICK(5);
-        if (prof) pc[7] += n_commit;
-    }
+        if (prof && com) pc[7] += n_commit;
 
-    const uint32_t nq = ps_wave_sum(S.num_queued), nv = ps_wave_sum(S.num_visited), np = ps_wave_sum(S.num_pruned);
-    if (lane == 0) {
-        E.status[qi] = S.err ? S.err : (found ? EX_OK : EX_PANIC);
-        E.end_cell[2 * qi] = R.end_row;
-        E.end_cell[2 * qi + 1] = R.end_off;
-        if (P.counters) {
-            if (prof) for (int k = 0; k < 8; ++k) P.prof[8 * (uint64_t)qi + k] = pc[k];
-            P.counters[4 * qi] = nq; P.counters[4 * qi + 1] = nv; P.counters[4 * qi + 2] = np; P.counters[4 * qi + 3] = steps;
+        // ---- searches that ended: results out, the group is free for the next query ----
+        if (__any(have && (found || S.err))) {
+            const bool fin = have && (found || S.err);
+            uint32_t nq = S.num_queued, nv = S.num_visited, np = S.num_pruned;
+#pragma unroll
+            for (int o = GS / 2; o; o >>= 1) {
+                nq += (uint32_t)__shfl_xor((int)nq, o, 64); nv += (uint32_t)__shfl_xor((int)nv, o, 64); np += (uint32_t)__shfl_xor((int)np, o, 64);
+            }
+            if (fin && gl == 0) {
+                E.status[qi] = S.err ? S.err : EX_OK;
+                E.end_cell[2 * qi] = R.end_row;
+                E.end_cell[2 * qi + 1] = R.end_off;
+                if (P.counters) {
+                    if (prof) for (int k = 0; k < 8; ++k) P.prof[8 * (uint64_t)qi + k] = pc[k];
+#if defined(POA_PS_PROF_FINE)
+                    if (prof) for (int k = 0; k < 6; ++k) P.prof[8 * (uint64_t)qi + k] = S.pf[k];
+#endif
+                    P.counters[4 * qi] = nq; P.counters[4 * qi + 1] = nv; P.counters[4 * qi + 2] = np; P.counters[4 * qi + 3] = steps;
+                }
+            }
+            if (fin) {
+                have = false; S.num_queued = S.num_visited = S.num_pruned = 0;
+                for (int k = 0; k < 8; ++k) pc[k] = 0;
+            }
         }
     }
-    }  // next query of this wave
 #undef PS_TICK
 }
 
