@@ -20,7 +20,7 @@
 #include "poa_graph.hpp"
 #include "poa_exact_kernel.hpp"
 #include "poa_wsearch.hpp"
-#include "poa_psearch.hpp"
+#include "poa_fsearch.hpp"
 #include "poa_kernels.hpp"
 #include "poa_forward_packed.hpp"
 #include "poa_forward_px.hpp"
@@ -216,7 +216,8 @@ struct poa_batch {
     DevBuf<uint32_t> d_pipeline_error;   // FwdParams::pipeline_error
     DevBuf<unsigned long long> d_ex_prof;
     DevBuf<uint32_t> d_ex_counters;    // wave search: num_queued, num_visited, num_pruned, steps per query
-    DevBuf<uint32_t> d_ex_logs;        // parallel-step search (poa_psearch.hpp): the lanes' logs, per resident wave
+    DevBuf<uint32_t> d_ex_logs;        // parallel-step search (poa_fsearch.hpp): the lanes' push logs, per resident wave
+    DevBuf<FlatGraph::RowRec> d_ex_rec; // per-row records of its lean step (FlatGraph::row_rec)
     bool exact_ready = false;
     uint32_t last_mode = 0;
 
@@ -559,6 +560,10 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
             HIP_TRY(hipMemcpy(b->d_ex_sym.p, row_sym.data(), row_sym.size(), hipMemcpyHostToDevice));
         }
         HIP_TRY(b->d_nbm_off.alloc(n + 1)); HIP_TRY(b->d_nbm.alloc(std::max<size_t>(fg.nbm.size(), 1)));
+        if (!fg.row_rec.empty()) {
+            HIP_TRY(b->d_ex_rec.alloc(fg.row_rec.size()));
+            HIP_TRY(hipMemcpy(b->d_ex_rec.p, fg.row_rec.data(), fg.row_rec.size() * sizeof(FlatGraph::RowRec), hipMemcpyHostToDevice));
+        }
         HIP_TRY(b->d_ex_status.alloc(std::max<uint32_t>(b->n_queries, 1)));
         HIP_TRY(b->d_ex_counters.alloc(4 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
         HIP_TRY(hipMemcpy(b->d_succ_off.p, fg.succ_row_off.data(), fg.succ_row_off.size() * 4, hipMemcpyHostToDevice));
@@ -821,7 +826,8 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             HIP_TRY(hipMemsetAsync(b->d_ex_head.p, 0xFF, (size_t)ch.count * 3 * b->ex_n_prio * 4, stream));
             ExactParams ep;
             ep.G = ExactGraph{fg.n, fg.start_row, fg.end_row, b->d_ex_sym.p, b->d_succ_off.p, b->d_succ_rows.p, b->d_dist_min.p,
-                              b->d_dist_max.p, b->d_exit_idx.p, fg.n_exit, b->d_nbm_off.p, b->d_nbm.p, b->d_node_row.p, b->d_sp_to_end.p};
+                              b->d_dist_max.p, b->d_exit_idx.p, fg.n_exit, b->d_nbm_off.p, b->d_nbm.p, b->d_node_row.p, b->d_sp_to_end.p,
+                              fg.row_rec.empty() ? nullptr : b->d_ex_rec.p};
             ep.first_query = ch.first; ep.n_queries = ch.count; ep.hybrid = hybrid; ep.dense_flags = b->d_flags.p;
             ep.qseq = b->d_qseq.p; ep.qoff = b->d_qoff.p; ep.pitch = b->d_pitch.p; ep.plane_off = PL.d_off.p;
             ep.planes = b->d_planes.p;
@@ -851,10 +857,11 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             const uint32_t graph_lds = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
             const char* impl = getenv("POA_EXACT_IMPL");
             const bool wave_search = !(impl && !strcmp(impl, "lane")) && win <= b->ex_n_prio;
-            const bool par_search = wave_search && !(impl && !strcmp(impl, "wave"));
+            // "flat": the parallel-step kernel (poa_fsearch.hpp) — bit-identical like the others, not the fastest yet
+            const bool par_search = wave_search && impl && !strcmp(impl, "flat");
             if (par_search) {
-                // the top entries of a stack expanded at once, one per lane (poa_psearch.hpp)
-                PSearchParams pp;
+                // the next entries in pop order expanded at once, one per lane, several queries per wave (poa_fsearch.hpp)
+                FSearchParams pp;
                 pp.E = ep;
                 pp.chunks = reinterpret_cast<ExU4*>(b->d_ex_pool.p);
                 pp.chunk_cap = b->ex_pool_cap / BQ_CHUNK;
@@ -863,8 +870,6 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 pp.counters = b->d_ex_counters.p;
                 pp.max_lanes = 63;   // (capped at the group's lanes below)
                 if (const char* lv = getenv("POA_PS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) pp.max_lanes = (uint32_t)v; }
-                pp.rmax = 8;
-                if (const char* lv = getenv("POA_PS_ROUNDS")) { const int v = atoi(lv); if (v >= 1 && v <= 64) pp.rmax = (uint32_t)v; }
                 pp.prof = nullptr;
                 if (getenv("POA_WS_PROF")) {
                     HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
@@ -872,28 +877,34 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 }
                 // Lanes per query: a step commits a dozen lanes on the benchmark's reads, and the kernel waits for memory more than it
                 // issues — so four searches share a wave (16 lanes each), all stepping through one instruction stream.
-                uint32_t group = 16;
-                if (const char* gv = getenv("POA_PS_GROUP")) { const int v = atoi(gv); if (v == 16 || v == 32 || v == 64) group = (uint32_t)v; }
+                pp.lean = (!fg.row_rec.empty() && !ends_free) ? 1u : 0u;
+                if (const char* lv = getenv("POA_PS_LEAN")) pp.lean = (pp.lean && atoi(lv) != 0) ? 1u : 0u;
+                const uint32_t group = pp.lean ? 8u : 16u;   // (the group sizes poa_fsearch.hpp is built for)
                 const uint32_t qpw = 64 / group;
                 pp.group = group;
-                if (pp.max_lanes > group - 1) pp.max_lanes = group - 1;
+                if (pp.max_lanes > group) pp.max_lanes = group;
                 // LDS of a block: the staged graph (shared by its waves) + per wave the descriptor rings of its queries and the
                 // logs / read sets / conflict tables of the step.  As many waves per block as fit 160 KB, at most 8 (two per SIMD:
                 // the kernel keeps a lane's search state in ~250 registers).
                 const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 160u * 1024u);
                 const uint64_t ring_b = ((uint64_t)qpw * 3 * win * 4 + 15) & ~15ull;
+                // the lean step reads one 32-byte record per row: those are staged (the arrays of the generic code, which it
+                // falls back to for a row in a thousand, stay in global memory); without records the generic code runs in log mode
+                const uint64_t rec_b = pp.lean ? ((sizeof(FlatGraph::RowRec) * (uint64_t)fg.n + 15) & ~15ull) : 0;
+                const uint64_t stage_b = pp.lean ? rec_b : graph_lds;
                 bool ring_lds = ring_b + ps_lds_bytes() <= lds_budget && !getenv("POA_WS_RING_GLOBAL");
                 uint64_t per_wave = (ring_lds ? ring_b : 0) + ps_lds_bytes();
-                bool stage = graph_lds + per_wave <= lds_budget;
+                bool stage = stage_b + per_wave <= lds_budget;
                 if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
-                uint32_t wpb = (uint32_t)std::min<uint64_t>(8, (lds_budget - (stage ? graph_lds : 0)) / per_wave);
+                uint32_t wpb = (uint32_t)std::min<uint64_t>(8, (lds_budget - (stage ? stage_b : 0)) / per_wave);
                 if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && (uint32_t)v <= wpb) wpb = (uint32_t)v; }
                 if (wpb < 1) return fail(POA_ERR_UNSUPPORTED, "exact replay: the step's logs do not fit the LDS");
-                pp.graph_lds = stage ? graph_lds : 0;
+                pp.graph_lds = (stage && !pp.lean) ? graph_lds : 0;
+                pp.rec_lds = (stage && pp.lean) ? (uint32_t)rec_b : 0;
                 pp.waves_per_block = wpb;
                 pp.ring_global = ring_lds ? nullptr : b->d_ex_head.p;   // [slots * 3 * ex_n_prio] holds slots * 3 * win
-                const uint32_t lds_bytes = pp.graph_lds + (uint32_t)(wpb * per_wave);
-                const void* kfn = reinterpret_cast<const void*>(poa_psearch_kernel);
+                const uint32_t lds_bytes = pp.graph_lds + pp.rec_lds + (uint32_t)(wpb * per_wave);
+                const void* kfn = pp.lean ? reinterpret_cast<const void*>(poa_fsearch_lean_kernel) : reinterpret_cast<const void*>(poa_fsearch_kernel);
                 if (lds_bytes > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 const uint32_t per_block = wpb * qpw;
                 uint32_t n_blocks = (ch.count + per_block - 1) / per_block;
@@ -918,7 +929,8 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 }
                 HIP_TRY(b->d_ex_logs.alloc((size_t)n_blocks * wpb * ps_scratch_words()));
                 pp.scratch = b->d_ex_logs.p;
-                hipLaunchKernelGGL(poa_psearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, pp);
+                if (pp.lean) hipLaunchKernelGGL(poa_fsearch_lean_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, pp);
+                else hipLaunchKernelGGL(poa_fsearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, pp);
             } else if (wave_search) {
                 WSearchParams wp;
                 wp.E = ep;

@@ -59,6 +59,7 @@ struct ExactGraph {  // row-indexed, read-only, shared by all queries
     // ends-free spans only (null for Global)
     const uint32_t* node_row;  // [n_rows] node index -> row (initial states are pushed by node index)
     const uint32_t* sp_to_end; // [n_rows] edges on the shortest path to the end row (0xFFFFFFFF: none)
+    const FlatGraph::RowRec* rec = nullptr;   // [n_rows] per-row records of the lean step (null: graph too large for them)
 };
 
 struct ExQEntry { uint32_t score, row, offset, next; };
@@ -131,6 +132,7 @@ struct SpecLane {
     uint32_t n_w = 0, n_m = 0, n_p = 0, n_pd = 0, flags = 0;
     uint32_t dq = 0, dv = 0, dp = 0, n_ent = 0;   // num_queued / num_visited / num_pruned of this lane's step; entries it processed
     uint32_t cur_f = 0, root_st = 0;              // the stack the step pops from
+    uint32_t flat = 0, min_child = 0xFFFFFFFFu;   // flat schedule: every push is logged; the lowest (priority << 2 | state) among them
     // logs: element k of this lane at base[k * stride]
     uint32_t* w_idx = nullptr; uint32_t* w_val = nullptr; uint32_t* m_x = nullptr; uint32_t* m_off = nullptr;
     ExU4* p = nullptr;                            // {score, row, offset, priority << 2 | state}
@@ -149,7 +151,7 @@ struct SpecLane {
 // that may be global or LDS compiles to FLAT loads, which wait for every outstanding vector-memory AND LDS operation
 // (they count on both counters): one such load in the middle of a batch of table reads serialises the batch.  With the
 // tag the access is a ds_read / ds_write and overlaps with the global loads in flight.
-enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4 };   // (4: logs and read sets of the log mode: SpecLane::w_*, m_*, rc, rm_*)
+enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4, EX_AS_REC_LDS = 8 };   // (4: logs and read sets of the log mode: SpecLane::w_*, m_*, rc, rm_*)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T> __device__ inline __attribute__((always_inline)) T ex_lds_load(const T* p) {
     return *(const __attribute__((address_space(3))) T*)p;
@@ -222,7 +224,7 @@ public:
 #endif
 #if defined(POA_PS_PROF_FINE) && defined(__HIP_DEVICE_COMPILE__)
 #define PF_START() do { pf_t = clock64(); } while (0)
-#define PF_TICK(k) do { const unsigned long long n_ = clock64(); pf[k] += n_ - pf_t; pf_t = n_; } while (0)
+#define PF_TICK(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = clock64(); pf[k] += n_ - pf_t; pf_t = n_; } while (0)
 #else
 #define PF_START() ((void)0)
 #define PF_TICK(k) ((void)0)
@@ -230,6 +232,7 @@ public:
 
 #if defined(POA_EXACT_DIAG)
     uint32_t why_complex[12] = {};
+    uint32_t pd_hist[2][8] = {};   // probe neighbours: distance below / above t (1, 2, 3-4 -> 4, 5-8 -> 5, > 8 -> 6, none -> 7)
     void sp_flag(uint32_t f, uint32_t why = 0) { sl.flags |= f; why_complex[why] += 1; }
 #else
     POA_HD void sp_flag(uint32_t f, uint32_t = 0) { sl.flags |= f; }
@@ -583,6 +586,12 @@ public:
         }
     }
     // remove the `pops` top entries of the current stack (pops <= d.n_top); `prev` = slot 0 of its top chunk
+    POA_HD void bq_drop_at(uint32_t prio, uint32_t st, BqDesc d, uint32_t pops, uint32_t prev) {
+        d.n_top -= pops;
+        if (d.n_top == 0 && prev != EX_NIL) { bq_release(d.top); d.top = prev; d.n_top = BQ_CHUNK - 1; }
+        if (bq_wr) rst(&W.bq_desc[3 * (prio & (W.bq_win - 1)) + st], d.top << 6 | d.n_top);
+        bq_live -= pops;
+    }
     POA_HD void bq_drop(uint32_t st, BqDesc d, uint32_t pops, uint32_t prev) {
         d.n_top -= pops;
         if (d.n_top == 0 && prev != EX_NIL) { bq_release(d.top); d.top = prev; d.n_top = BQ_CHUNK - 1; }
@@ -611,6 +620,13 @@ public:
     POA_HD void spec_queue(uint32_t prio, uint32_t st, uint32_t score, uint32_t row, uint32_t off) {
         if (prio >= (1u << 26)) { sp_flag(SPF_COMPLEX, 9); return; }
         const uint32_t key = prio << 2 | st;
+        if (sl.flat) {
+            if (sl.n_p >= SP_KP) { sp_flag(SPF_COMPLEX, 5); return; }
+            sl.p[sl.n_p * sl.stride] = ExU4{score, row, off, key};
+            sl.n_p += 1;
+            if (key < sl.min_child) sl.min_child = key;
+            return;
+        }
         if (prio < sl.cur_f || (prio == sl.cur_f && st <= sl.root_st)) {
             if (sl.n_pd >= SP_KPD) { sp_flag(SPF_COMPLEX, 6); return; }
 #pragma unroll
@@ -885,6 +901,11 @@ public:
         const uint64_t hi = (t & 63) != 63 ? (P.w1 & (~0ull << ((t & 63) + 1))) : 0ull;
         if (hi) nxt = wi * 64 + (uint32_t)ctz64(hi);
         else if (wi + 1 < W.wpn && (P.sum >> (wi + 1))) nxt = reached_from(ex, (wi + 1) * 64);
+#if defined(POA_EXACT_DIAG)
+        { const uint32_t dl = prev == EX_NIL ? 99 : t - prev, dr = (at_t || nxt == EX_NIL) ? 99 : nxt - t;
+          const uint32_t bl = dl == 99 ? 7 : dl > 8 ? 6 : dl > 4 ? 5 : dl > 2 ? 4 : dl, br = dr == 99 ? 7 : dr > 8 ? 6 : dr > 4 ? 5 : dr > 2 ? 4 : dr;
+          pd_hist[0][bl] += 1; pd_hist[1][br] += 1; }
+#endif
         // what the decision read of the exit row: the marks between the two neighbours and the scores at them (reached at t:
         // the neighbour above is not looked at, reached.rs:139)
         if (spec) {
@@ -1238,6 +1259,369 @@ public:
         sl.dq = num_queued - q0; sl.dv = num_visited - v0; sl.dp = num_pruned - p0;
         num_queued = q0; num_visited = v0; num_pruned = p0;
     }
+    // ---- the lean step (poa_fsearch.hpp): one entry, or one more row of a greedy extension, per lane and step --------------------
+    // Straight-line code over the per-row records (FlatGraph::RowRec) for the shapes that make up nearly all of a search: rows
+    // with one or two successors, at most two bubbles ahead with exits a (nearly) fixed distance away.  Every load of a phase is
+    // issued before the first use (own cell, relax targets, the words of the reached sets; then the words the nearest marks lie
+    // in; then the scores at them), all decisions follow, then the writes — so nothing a lane reads can be its own write, and a
+    // step costs the same few memory round trips whatever the lane met.  Whatever does not fit is flagged SPF_COMPLEX: the
+    // entry (or the rest of its extension) takes the generic code of this file, sequentially.
+    //
+    // A greedy extension (dfa.rs:138-250) is not walked to its end by the lane that started it: after every matched base the
+    // lane hands back the state of the walk (LeanWalk) and the next step of its group goes on from there — no lane of a wave
+    // waits for another one's long extension.
+    struct LeanWalk {
+        uint32_t on = 0;          // an extension is under way: (r, j) is the row / offset whose successors are looked at next
+        uint32_t r = 0, j = 0, k = 0, g = 0;   // k: index of the next successor; g: the score of the extension
+        uint32_t iopen = 0;       // the insertion I[r][j+1] was already relaxed by a mismatch event of this row
+        uint32_t sib_n = 0;       // rows left behind with their second successor still to look at (dfa.rs:86-134, the stack)
+        uint32_t sib_r[2] = {0, 0}, sib_j[2] = {0, 0}, sib_io[2] = {0, 0};
+        uint32_t dv = 0;          // rows this extension has visited so far (AstarResult::num_visited counts them when it ends)
+    };
+    struct LProbe {
+        uint32_t on;              // 0: nothing to test
+        uint32_t e, x, tmin, tmax, mde;
+        uint64_t S, W0, W1;       // summary (which words are non-empty), the words of tmin and tmax
+        uint32_t cw[5];           // Match scores of the exit row at tmin-1 .. tmax+1
+        uint32_t prev, nxt;       // nearest marks below tmin / above tmax (EX_NIL: none)
+        uint32_t wl, wu;          // words they lie in when not W0 / W1 (EX_NIL: no need)
+        uint64_t Wl, Wu;
+        uint32_t sp, sn;          // scores at prev / nxt
+    };
+    POA_HD FlatGraph::RowRec lrec(uint32_t row) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((AS & EX_AS_REC_LDS) != 0) {
+            typedef __attribute__((address_space(3))) const uint4 lds_cu4;
+            const uint4 a = ((lds_cu4*)G.rec)[2 * row], b = ((lds_cu4*)G.rec)[2 * row + 1];
+            FlatGraph::RowRec rr;
+            __builtin_memcpy(&rr, &a, 16); __builtin_memcpy(reinterpret_cast<char*>(&rr) + 16, &b, 16);
+            return rr;
+        }
+#endif
+        return G.rec[row];
+    }
+    POA_HD uint32_t lh(uint32_t dmn, uint32_t dmx, uint32_t off, uint32_t st) const {   // h() over a record's distances
+        if (C.heuristic == EX_H_DIJKSTRA) return 0;
+        const uint32_t tmin = off + dmn, tmax = off + dmx;
+        uint32_t gap;
+        if (tmin > L) { gap = tmin - L; if (st != EX_ST_D) st = EX_ST_M; }
+        else if (tmax < L) { gap = L - tmax; if (st != EX_ST_I) st = EX_ST_M; }
+        else gap = 0;
+        return gap_cost(st, gap);
+    }
+    // probe of bubble b (0 / 1) of the row of `rr` for a state at offset q
+    POA_HD void lp_setup(LProbe& P, const FlatGraph::RowRec& rr, uint32_t b, uint32_t q, bool enabled) const {
+        const uint32_t e = b ? rr.e1 : rr.e0;
+        P.e = e; P.x = b ? rr.x1 : rr.x0; P.tmin = q + (b ? rr.d1min : rr.d0min); P.tmax = q + (b ? rr.d1max : rr.d0max); P.mde = b ? rr.mde1 : rr.mde0;
+        P.on = (enabled && e != 0xFFFFu && P.tmax <= L) ? 1u : 0u;    // reached.rs:63-65: tmax > len -> can improve
+        P.S = P.W0 = P.W1 = P.Wl = P.Wu = 0; P.prev = P.nxt = P.wl = P.wu = EX_NIL; P.sp = P.sn = EX_INF;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) P.cw[k] = EX_INF;
+    }
+    POA_HD void lp_load1(LProbe& P) const {
+        if (!P.on) return;
+        P.S = W.rsum[(uint64_t)P.x * W.swpn];
+        P.W0 = W.reached[(uint64_t)P.x * W.wpn + (P.tmin >> 6)];
+        P.W1 = W.reached[(uint64_t)P.x * W.wpn + (P.tmax >> 6)];
+        const uint32_t n = P.tmax - P.tmin + 3;   // cw[k]: offset tmin - 1 + k, up to tmax + 1 (< pitch: checked by the caller)
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) if (k < n && (k != 0 || P.tmin != 0)) P.cw[k] = W.T[cix(P.e, P.tmin + k - 1, EX_ST_M)];
+    }
+    // nearest marks from the words at hand; else the word to look in next
+    POA_HD void lp_locate1(LProbe& P) const {
+        if (!P.on || P.S == 0) return;
+        const uint32_t w0 = P.tmin >> 6, w1 = P.tmax >> 6;
+        const uint64_t below = (P.tmin & 63) ? (P.W0 & (~0ull >> (64 - (P.tmin & 63)))) : 0ull;
+        if (below) P.prev = w0 * 64 + 63 - (uint32_t)clz64(below);
+        else if (w0) { const uint64_t sb = P.S & (~0ull >> (64 - w0)); if (sb) P.wl = 63 - (uint32_t)clz64(sb); }
+        const uint64_t above = (P.tmax & 63) != 63 ? (P.W1 & (~0ull << ((P.tmax & 63) + 1))) : 0ull;
+        if (above) P.nxt = w1 * 64 + (uint32_t)ctz64(above);
+        else if (w1 + 1 < W.wpn && w1 + 1 < 64) { const uint64_t sa = P.S >> (w1 + 1); if (sa) P.wu = w1 + 1 + (uint32_t)ctz64(sa); }
+    }
+    POA_HD void lp_load2(LProbe& P) const {
+        if (P.wl != EX_NIL) P.Wl = W.reached[(uint64_t)P.x * W.wpn + P.wl];
+        if (P.wu != EX_NIL) P.Wu = W.reached[(uint64_t)P.x * W.wpn + P.wu];
+    }
+    POA_HD void lp_locate2(LProbe& P) const {
+        if (P.wl != EX_NIL && P.Wl) P.prev = P.wl * 64 + 63 - (uint32_t)clz64(P.Wl);
+        if (P.wu != EX_NIL && P.Wu) P.nxt = P.wu * 64 + (uint32_t)ctz64(P.Wu);
+    }
+    POA_HD void lp_load3(LProbe& P) const {
+        // scores at the two neighbours: next to the range they are loaded already
+        if (P.prev != EX_NIL) { if (P.prev + 1 == P.tmin) P.sp = P.cw[0]; else if (P.prev < W.pitch) P.sp = W.T[cix(P.e, P.prev, EX_ST_M)]; }
+        if (P.nxt != EX_NIL) {
+            const uint32_t wd = P.tmax - P.tmin;
+            if (P.nxt == P.tmax + 1) P.sn = wd == 0 ? P.cw[2] : wd == 1 ? P.cw[3] : P.cw[4];
+            else if (P.nxt < W.pitch) P.sn = W.T[cix(P.e, P.nxt, EX_ST_M)];
+        }
+    }
+    // reached.rs:191-255 on the values at hand: left / right = (offset, score) of the nearest marks, EX_NIL: none
+    POA_HD bool lp_improve_at(uint32_t t, uint32_t score, uint32_t left, uint32_t ls, uint32_t right, uint32_t rs, uint32_t mde) const {
+        if (left != EX_NIL && right != EX_NIL) {
+            const uint32_t fl = ls + gap_cost(EX_ST_M, t - left), fr = rs + gap_cost(EX_ST_M, right - t);
+            return score < ((right - t > mde) ? fl : (fl < fr ? fl : fr));
+        }
+        if (right != EX_NIL) return (right - t > mde) ? true : score < rs + gap_cost(EX_ST_M, right - t);
+        if (left != EX_NIL) return score < ls + gap_cost(EX_ST_M, t - left);
+        return true;
+    }
+    // reached.rs:38-189 over the probe's data.  0: can improve; 2: pruned; 3: a mark without a score — the generic code reports
+    // what the reference would.  Notes what the decision depended on.
+    POA_HD uint32_t lp_decide(const LProbe& P, uint32_t g, uint32_t st) {
+        if (!P.on) return 0;
+        if (P.S == 0) { if (spec) note_marks(P.x, 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
+        if (spec) {
+            note_marks(P.x, P.prev == EX_NIL ? 0u : P.prev, P.nxt);
+            if (P.prev != EX_NIL && P.prev < W.pitch) note_cell(cix(P.e, P.prev, EX_ST_M));
+            if (P.nxt != EX_NIL && P.nxt < W.pitch) note_cell(cix(P.e, P.nxt, EX_ST_M));
+        }
+        if ((P.prev != EX_NIL && P.sp == EX_INF) || (P.nxt != EX_NIL && P.sn == EX_INF) || g >= 0xFFFF0000u) return 3;
+        uint32_t prev = P.prev, ps = P.sp;
+        bool have_last = false; uint32_t last_offset = 0;
+        const uint32_t n_in = P.tmax - P.tmin + 1;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+            if (k >= n_in) break;
+            const uint32_t next = P.tmin + k;
+            const uint64_t wd = (next >> 6) == (P.tmin >> 6) ? P.W0 : P.W1;
+            if (!((wd >> (next & 63)) & 1)) continue;
+            const uint32_t ns = P.cw[k + 1];
+            if (spec) note_cell(cix(P.e, next, EX_ST_M));
+            if (ns == EX_INF) return 3;
+            const uint32_t offset1 = prev != EX_NIL ? (P.tmin > prev + 1 ? P.tmin : prev + 1) : P.tmin;
+            if (st == EX_ST_D && ns + C.o > g) return 0;
+            if (prev != EX_NIL && st == EX_ST_I && ps + C.o > g) return 0;
+            if (lp_improve_at(offset1, g, prev, ps, next, ns, P.mde)) return 0;
+            const uint32_t nm1 = next - 1u;
+            const uint32_t mx = P.tmin > nm1 ? P.tmin : nm1;
+            const uint32_t offset2 = P.tmax < mx ? P.tmax : mx;
+            if (offset2 != offset1 && lp_improve_at(offset2, g, prev, ps, next, ns, P.mde)) return 0;
+            prev = next; ps = ns;
+            last_offset = offset2; have_last = true;
+        }
+        if (!have_last && lp_improve_at(P.tmin, g, prev, ps, P.nxt, P.sn, P.mde)) return 0;
+        if ((!have_last || last_offset < P.tmax) && lp_improve_at(P.tmax, g, prev, ps, P.nxt, P.sn, P.mde)) return 0;
+        if (prev != EX_NIL && st == EX_ST_I && ps + C.o > g) return 0;
+        return 2;
+    }
+    // queue a state whose row's record is at hand (the heuristic reads its distances)
+    POA_HD void lqueue(uint32_t row, uint32_t dmn, uint32_t dmx, uint32_t off, uint32_t st, uint32_t score) {
+        num_queued += 1;
+        spec_queue(score + lh(dmn, dmx, off, st), st, score, row, off);
+    }
+
+    // One step of a lane in log mode: the entry (g, v, j, st) if wk.on == 0, else one more row of the extension wk.  On return
+    // sl.flags has SPF_COMPLEX (nothing was logged: the generic code takes over — the entry, or the extension from wk on) or not;
+    // wk.on says whether the extension goes on.  Counters: num_queued / num_visited / num_pruned of the search are advanced.
+    POA_HD void lean_unit(uint32_t g, uint32_t v, uint32_t j, uint32_t st, LeanWalk& wk) {
+        PF_START();
+        const bool cont = wk.on != 0;
+        const uint32_t r = cont ? wk.r : v, q = cont ? wk.j : j, k0 = cont ? wk.k : 0u, gg = cont ? wk.g : g;
+        const uint32_t est = cont ? (uint32_t)EX_ST_M : st;
+        if (G.rec == nullptr || C.ends_free || W.swpn != 1 || q + 4 >= W.pitch || gg >= 0xFFFF0000u) { sp_flag(SPF_COMPLEX, 10); return; }
+        const FlatGraph::RowRec rr = lrec(r);
+        const uint32_t fl = rr.flags;
+        if ((fl & FlatGraph::RR_END) || (est != EX_ST_I && !(fl & FlatGraph::RR_SUCC_OK)) || (!cont && C.prune && !(fl & FlatGraph::RR_PROBE_OK))) { sp_flag(SPF_COMPLEX, 10); return; }
+        if (est == EX_ST_M && !cont && q == 0 && L != 0 && rr.sym == seq[0]) { sp_flag(SPF_COMPLEX, 10); return; }   // dfa.rs:146-167
+        const uint32_t c0 = rr.c0, c1 = (fl & FlatGraph::RR_HAS_C1) ? (uint32_t)rr.c1 : EX_NIL;
+        // ---- Match state / extension: which successors match the query symbol; the first one from k0 on is followed ----
+        bool m0 = false, m1 = false;
+        uint32_t cm = EX_NIL;   // the successor followed (probes of its row are loaded)
+        FlatGraph::RowRec rm{};
+        if (est == EX_ST_M && q < L) {
+            const uint8_t qc = seq[q];
+            m0 = k0 == 0 && rr.sym0 == qc; m1 = c1 != EX_NIL && rr.sym1 == qc;
+            cm = m0 ? c0 : (m1 ? c1 : EX_NIL);
+            if (cm != EX_NIL) {
+                rm = lrec(cm);
+                if (!(rm.flags & FlatGraph::RR_PROBE_OK)) { sp_flag(SPF_COMPLEX, 10); return; }
+            }
+        }
+        // distances to the end of the rows that may be queued (heuristic)
+        const FlatGraph::RowRec r0 = (est != EX_ST_I) ? (cm == c0 && cm != EX_NIL ? rm : lrec(c0)) : rr;
+        const FlatGraph::RowRec r1 = (est != EX_ST_I && c1 != EX_NIL) ? (cm == c1 ? rm : lrec(c1)) : rr;
+        // ---- probes: of the state itself (a fresh entry), of the successor the extension would step on ----
+        LProbe P0, P1, Q0, Q1;
+        lp_setup(P0, rr, 0, q, !cont && C.prune != 0); lp_setup(P1, rr, 1, q, !cont && C.prune != 0);
+        lp_setup(Q0, rm, 0, q + 1, cm != EX_NIL); lp_setup(Q1, rm, 1, q + 1, cm != EX_NIL);   // (the test inside the extension is not subject to enable_pruning, dfa.rs:185)
+        PF_TICK(0);
+        // ---- phase 1: every cell the step may look at, the words of the probes ----
+        const uint32_t i_own = cix(r, q, est);
+        uint32_t own = cont ? gg : W.T[i_own];
+        uint32_t iA = i_own, iB = i_own, iC = i_own, iD = i_own, iE = i_own;
+        if (est == EX_ST_M) {
+            if (q < L) { iA = cix(c0, q + 1, EX_ST_M); iB = cix(r, q + 1, EX_ST_I); iC = cix(c0, q, EX_ST_D); if (c1 != EX_NIL) { iD = cix(c1, q + 1, EX_ST_M); iE = cix(c1, q, EX_ST_D); } }
+            else { iC = cix(c0, q, EX_ST_D); if (c1 != EX_NIL) iE = cix(c1, q, EX_ST_D); }
+        } else if (est == EX_ST_I) { iA = cix(r, q, EX_ST_M); iB = cix(r, q < L ? q + 1 : q, EX_ST_I); }
+        else { iA = cix(r, q, EX_ST_M); iC = cix(c0, q, EX_ST_D); if (c1 != EX_NIL) iE = cix(c1, q, EX_ST_D); }
+        uint32_t vA = W.T[iA], vB = W.T[iB], vC = W.T[iC], vD = W.T[iD], vE = W.T[iE];
+        lp_load1(P0); lp_load1(P1); lp_load1(Q0); lp_load1(Q1);
+        PF_TICK(1);
+        // ---- phase 2: the words the nearest marks lie in; phase 3: the scores there ----
+        lp_locate1(P0); lp_locate1(P1); lp_locate1(Q0); lp_locate1(Q1);
+        lp_load2(P0); lp_load2(P1); lp_load2(Q0); lp_load2(Q1);
+        PF_TICK(2);
+        lp_locate2(P0); lp_locate2(P1); lp_locate2(Q0); lp_locate2(Q1);
+        lp_load3(P0); lp_load3(P1); lp_load3(Q0); lp_load3(Q1);
+        PF_TICK(3);
+        // ---- decisions ----
+        if (spec) {
+            if (!cont) note_cell(i_own);
+            if (est == EX_ST_M) {
+                if (q < L) { if (k0 == 0) { note_cell(iA); note_cell(iC); } note_cell(iB); if (c1 != EX_NIL) { note_cell(iD); note_cell(iE); } }
+                else { if (k0 == 0) note_cell(iC); if (c1 != EX_NIL) note_cell(iE); }
+            } else if (est == EX_ST_I) { note_cell(iA); if (q < L) note_cell(iB); }
+            else { note_cell(iA); note_cell(iC); if (c1 != EX_NIL) note_cell(iE); }
+        }
+        PF_TICK(4);
+        if (!cont) {
+            if (gg > own) return;                                   // stale (astar.rs:146)
+            uint32_t pr = lp_decide(P0, gg, est);
+            if (pr == 0) pr = lp_decide(P1, gg, est);
+            if (pr == 3) { sp_flag(SPF_COMPLEX, 10); return; }
+            if (sl.flags & SPF_COMPLEX) return;
+            if (pr == 2) { num_pruned += 1; return; }               // astar.rs:155-158
+            mark_reached(r, q, est);                                // astar.rs:160 (Match states at bubble exits)
+            num_visited += 1;
+        }
+        if (est == EX_ST_I) {   // expand_all, gap_affine.rs:307-322
+            if (gg < vA) { wr(r, q, EX_ST_M, gg); lqueue(r, rr.dmin, rr.dmax, q, EX_ST_M, gg); }
+            const uint32_t ns = gg + C.e;
+            if (q < L && ns < vB) { wr(r, q + 1, EX_ST_I, ns); lqueue(r, rr.dmin, rr.dmax, q + 1, EX_ST_I, ns); }
+            return;
+        }
+        if (est == EX_ST_D) {   // expand_all, gap_affine.rs:323-340
+            if (gg < vA) { wr(r, q, EX_ST_M, gg); lqueue(r, rr.dmin, rr.dmax, q, EX_ST_M, gg); }
+            const uint32_t ns = gg + C.e;
+            if (ns < vC) { wr(c0, q, EX_ST_D, ns); lqueue(c0, r0.dmin, r0.dmax, q, EX_ST_D, ns); }
+            if (c1 != EX_NIL && ns < vE) { wr(c1, q, EX_ST_D, ns); lqueue(c1, r1.dmin, r1.dmax, q, EX_ST_D, ns); }
+            return;
+        }
+        PF_TICK(5);
+        // ---- Match state: the successors of (r, q) from k0 on, in order (dfa.rs:210-250) ----
+        const uint32_t nm = gg + C.x, ng = gg + C.o + C.e;
+        uint32_t io = cont ? wk.iopen : 0u;
+        bool descended = false;
+        uint32_t kk = k0;
+        const uint32_t nchild = c1 != EX_NIL ? 2u : 1u;
+#pragma unroll
+        for (uint32_t i = 0; i < 2; ++i) {
+            if (i < k0 || i >= nchild || descended || kk != i) continue;
+            const uint32_t c = i ? c1 : c0;
+            const FlatGraph::RowRec& rc = i ? r1 : r0;
+            const uint32_t vM = i ? vD : vA, vDd = i ? vE : vC;
+            if (q >= L) {   // QueryEnd -> expand_query_end (gap_affine.rs:369-391)
+                if (ng < vDd) { wr(c, q, EX_ST_D, ng); lqueue(c, rc.dmin, rc.dmax, q, EX_ST_D, ng); }
+                kk = i + 1;
+                continue;
+            }
+            const bool mt = i ? m1 : m0;
+            if (!mt) {      // Mismatch -> expand_mismatch (gap_affine.rs:393-430)
+                if (nm < vM) { wr(c, q + 1, EX_ST_M, nm); lqueue(c, rc.dmin, rc.dmax, q + 1, EX_ST_M, nm); }
+                if (!io) { if (ng < vB) { wr(r, q + 1, EX_ST_I, ng); lqueue(r, rr.dmin, rr.dmax, q + 1, EX_ST_I, ng); } io = 1; }
+                if (ng < vDd) { wr(c, q, EX_ST_D, ng); lqueue(c, rc.dmin, rc.dmax, q, EX_ST_D, ng); }
+                kk = i + 1;
+                continue;
+            }
+            if (c != cm) break;   // a second successor to follow: its probes are not at hand — the next step starts here (kk == i)
+            kk = i + 1;
+            if (!(gg < vM)) continue;                               // already there with this score or better (dfa.rs:242)
+            wr(c, q + 1, EX_ST_M, gg);
+            uint32_t pr = lp_decide(Q0, gg, EX_ST_M);
+            if (pr == 0) pr = lp_decide(Q1, gg, EX_ST_M);
+            if (pr == 3) { sp_flag(SPF_COMPLEX, 10); return; }
+            if (sl.flags & SPF_COMPLEX) return;
+            if (pr == 2) { num_pruned_dfa += 1; continue; }        // scored, not extended (dfa.rs:185-188)
+            mark_reached(c, q + 1, EX_ST_M);
+            num_visited += 1; wk.dv += 1;                           // (dfa.num_visited, added when the extension ends: astar.rs:205)
+            descended = true;
+        }
+        if (sl.flags & SPF_COMPLEX) return;
+        if (descended) {
+            // the row just stepped on is looked at next; the row left behind stays on the stack if it has a successor left
+            if (kk < nchild) {
+                if (wk.sib_n >= 2) { sp_flag(SPF_COMPLEX, 7); return; }
+#pragma unroll
+                for (uint32_t s2 = 0; s2 < 2; ++s2) if (s2 == wk.sib_n) { wk.sib_r[s2] = r; wk.sib_j[s2] = q; wk.sib_io[s2] = io; }
+                wk.sib_n += 1;
+            }
+            wk.on = 1; wk.r = cm; wk.j = q + 1; wk.k = 0; wk.g = gg; wk.iopen = 0;
+            return;
+        }
+        if (kk < nchild) { wk.on = 1; wk.r = r; wk.j = q; wk.k = kk; wk.g = gg; wk.iopen = io; return; }   // (second successor to follow next)
+        // successors exhausted: back to the last row left behind, if any (its second successor is looked at next)
+        if (wk.sib_n) {
+            wk.sib_n -= 1;
+            uint32_t br = 0, bj = 0, bio = 0;
+#pragma unroll
+            for (uint32_t s2 = 0; s2 < 2; ++s2) if (s2 == wk.sib_n) { br = wk.sib_r[s2]; bj = wk.sib_j[s2]; bio = wk.sib_io[s2]; }
+            wk.on = 1; wk.r = br; wk.j = bj; wk.k = 1; wk.g = gg; wk.iopen = bio;
+            return;
+        }
+        wk.on = 0;
+    }
+    // The generic code finishes an extension the lean step gave up on (direct mode): the walk's state becomes the stack of
+    // dfa_extend.  true: the search ends here.
+    POA_HD bool lean_walk_generic(LeanWalk& wk, ExactResult& R, uint32_t& end_score) {
+        dfa_score = wk.g; dfa_visited = 0;
+        sp = 0;
+        // the rows left behind, oldest first, each with its second successor next
+        for (uint32_t s2 = 0; s2 < wk.sib_n; ++s2) {
+            const ExStackEntry en{wk.sib_r[s2], wk.sib_j[s2], gld(&G.succ_off[wk.sib_r[s2]]) + 1};
+            if (sp != 0) { if (sp >= W.stack_cap) { err = EX_POOL_FULL; return false; } W.stack[sp - 1] = dfa_top; }
+            dfa_top = en; sp += 1;
+        }
+        {
+            const ExStackEntry en{wk.r, wk.j, gld(&G.succ_off[wk.r]) + wk.k};
+            if (sp != 0) { if (sp >= W.stack_cap) { err = EX_POOL_FULL; return false; } W.stack[sp - 1] = dfa_top; }
+            dfa_top = en; sp += 1;
+        }
+        // (the insertion of the row on top may have been relaxed already: relaxing it again cannot succeed — same value)
+        const uint32_t dv0 = wk.dv;
+        wk = LeanWalk();
+        if (dfa_events(dfa_score, R, end_score)) { num_visited -= dv0; return true; }   // skipped by `break 'main` (astar.rs:172,:205)
+        num_visited += dfa_visited;
+        return false;
+    }
+
+    // ---- flat schedule: ONE entry per lane and step, everything it pushes is logged (poa_fsearch.hpp) ----------------------------
+    POA_HD void spec_entry(uint32_t g, uint32_t v, uint32_t j, uint32_t st, ExactResult& R, uint32_t& end_score, bool use_fast = true) {
+        sl.n_w = sl.n_m = sl.n_p = sl.n_pd = 0; sl.flags = 0; sl.n_rc = sl.n_rm = 0; sl.n_ent = 0; sl.wmask = sl.mmask = 0;
+        sl.flat = 1; sl.min_child = 0xFFFFFFFFu;
+        rc_x = rs_x = EX_NIL;
+        const uint32_t q0 = num_queued, v0 = num_visited, p0 = num_pruned;
+        spec = true;
+        FastItem F{0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t sk = use_fast ? inspect_fast(g, v, j, st, F) : 3u;
+        if (sk == 3 && !err && !(sl.flags & SPF_COMPLEX)) sk = inspect_skip(g, v, j, st);
+        bool found = false;
+        if (!err && !(sl.flags & SPF_COMPLEX)) {
+            if (sk == 2) num_pruned += 1;
+            if (sk == 0) found = F.kind ? process_fast(g, v, j, st, F, R, end_score) : process_popped(g, v, j, st, R, end_score);
+        }
+        spec = false; sl.flat = 0;
+        sl.n_ent = 1;
+        if (err) { sl.flags |= SPF_COMPLEX; err = EX_OK; }   // the sequential code meets the same condition and reports it
+        else if (found) sl.flags |= SPF_FOUND;
+        sl.dq = num_queued - q0; sl.dv = num_visited - v0; sl.dp = num_pruned - p0;
+        num_queued = q0; num_visited = v0; num_pruned = p0;
+    }
+
+    // the lean step of one lane in log mode: wk is advanced only if the step stands (no SPF_COMPLEX)
+    POA_HD void spec_lean(uint32_t g, uint32_t v, uint32_t j, uint32_t st, LeanWalk& wk) {
+        sl.n_w = sl.n_m = sl.n_p = sl.n_pd = 0; sl.flags = 0; sl.n_rc = sl.n_rm = 0; sl.n_ent = 1; sl.wmask = sl.mmask = 0;
+        sl.flat = 1; sl.min_child = 0xFFFFFFFFu;
+        const uint32_t q0 = num_queued, v0 = num_visited, p0 = num_pruned;
+        spec = true;
+        LeanWalk w2 = wk;
+        lean_unit(g, v, j, st, w2);
+        spec = false; sl.flat = 0;
+        if (err) { sl.flags |= SPF_COMPLEX; err = EX_OK; }
+        if (sl.flags & SPF_COMPLEX) { sl.n_w = sl.n_m = sl.n_p = 0; sl.min_child = 0xFFFFFFFFu; sl.dq = sl.dv = sl.dp = 0; }
+        else { wk = w2; sl.dq = num_queued - q0; sl.dv = num_visited - v0; sl.dp = num_pruned - p0; }
+        num_queued = q0; num_visited = v0; num_pruned = p0;
+    }
+
     // did this lane read a cell or a mark that `o` (an earlier lane of the step) logged a write to?
     POA_HD bool spec_reads_what(const SpecLane& o) const {
         for (uint32_t a = 0; a < sl.n_rc; ++a)
@@ -1331,6 +1715,113 @@ public:
             }
         }
         delete[] buf; delete[] ls; delete[] rs; delete[] es;
+        R.status = err ? err : (found ? EX_OK : EX_PANIC);
+        R.score = end_score;
+        R.num_queued = num_queued; R.num_visited = num_visited; R.num_pruned = num_pruned;
+        return R;
+    }
+
+    // The schedule of the wave kernel poa_fsearch.hpp, one lane after the other (host build: its executable specification).
+    // A step offers the next `lanes` entries in the queue's pop order — the stacks of the current bucket one after the other,
+    // Match, Deletion, Insertion (gap_affine.rs:954-966), each from its top — one entry per lane, processed in log mode against
+    // the table as the step found it.  Committed: the lanes before the first one that read what an earlier lane wrote or needs
+    // the sequential code, and before the first one whose (priority, state) is not below that of something an earlier
+    // committed lane pushed (that push would be popped first).  Every push goes to the queue.
+    ExactResult run_flat(uint32_t lanes, bool use_fast = true, bool lean = false) {
+        ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, L};
+        push_initial_states();
+        uint32_t end_score = EX_INF;
+        bool found = false;
+        if (lanes > 63) lanes = 63;
+        struct LaneBuf { uint32_t w_idx[SP_KW], w_val[SP_KW], m_x[SP_KM], m_off[SP_KM], rm_x[SP_KRM], rm_lo[SP_KRM], rm_hi[SP_KRM]; uint16_t rc[SP_KRC]; ExU4 p[SP_KP]; ExStackEntry ds[SP_KDS]; };
+        LaneBuf* buf = new LaneBuf[64];
+        SpecLane* ls = new SpecLane[64];
+        ExactResult* rs = new ExactResult[64];
+        uint32_t* es = new uint32_t[64];
+        ExU4* ent = new ExU4[64];
+        uint32_t* est = new uint32_t[64];
+        LeanWalk* wks = new LeanWalk[64];
+        LeanWalk walk;   // the extension under way (lean steps): the first lane of the next step goes on with it
+        while (!found && !err) {
+            uint32_t st0 = 0; BqDesc d0{0, 0};
+            const bool have_q = bq_current(st0, d0);
+            if (!have_q && !walk.on) { err = EX_PANIC; break; }
+            par_steps += 1;
+            const uint32_t f = layer_min;
+            // the entries offered: the extension under way first; then the stacks st0.. of bucket f — a stack is left for the
+            // next one only when it is taken whole
+            uint32_t n_off = 0, taken[3] = {0, 0, 0}, prevc[3] = {EX_NIL, EX_NIL, EX_NIL}, beg[3] = {0, 0, 0};
+            BqDesc ds3[3] = {BqDesc{0, 0}, BqDesc{0, 0}, BqDesc{0, 0}};
+            const uint32_t w_on = walk.on ? 1u : 0u;
+            if (w_on) { ent[0] = ExU4{0, 0, 0, 0}; est[0] = 0; n_off = 1; }
+            for (uint32_t s2 = st0; have_q && s2 < 3 && n_off < lanes; ++s2) {
+                const uint32_t dw = W.bq_desc[3 * (f & (W.bq_win - 1)) + s2];
+                beg[s2] = n_off;
+                if (dw == BQ_EMPTY || (dw & 63u) == 0) continue;
+                ds3[s2] = BqDesc{dw >> 6, dw & 63u};
+                const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * ds3[s2].top;
+                prevc[s2] = ch[0].x;
+                const uint32_t take = ds3[s2].n_top < lanes - n_off ? ds3[s2].n_top : lanes - n_off;
+                for (uint32_t i = 0; i < take; ++i) { ent[n_off] = ch[ds3[s2].n_top - i]; est[n_off] = s2; n_off += 1; }
+                taken[s2] = take;
+                if (take < ds3[s2].n_top || prevc[s2] != EX_NIL) { for (uint32_t s3 = s2 + 1; s3 < 3; ++s3) beg[s3] = n_off; break; }   // more of this stack is left
+                for (uint32_t s3 = s2 + 1; s3 < 3; ++s3) beg[s3] = n_off;
+            }
+            uint32_t n_commit = 0, limit = n_off;
+            bool seq0 = false;
+            for (uint32_t i = 0; i < n_off && i < limit; ++i) {
+                sl = SpecLane();
+                sl.w_idx = buf[i].w_idx; sl.w_val = buf[i].w_val; sl.m_x = buf[i].m_x; sl.m_off = buf[i].m_off; sl.p = buf[i].p; sl.stride = 1;
+                sl.rc = buf[i].rc; sl.rm_x = buf[i].rm_x; sl.rm_lo = buf[i].rm_lo; sl.rm_hi = buf[i].rm_hi; sl.dstack = buf[i].ds;
+                rs[i] = R; es[i] = end_score;
+                wks[i] = (i == 0 && w_on) ? walk : LeanWalk();
+                if (lean) spec_lean(ent[i].x, ent[i].y, ent[i].z, est[i], wks[i]);
+                else spec_entry(ent[i].x, ent[i].y, ent[i].z, est[i], rs[i], es[i], use_fast);
+                ls[i] = sl;
+                bool cut_before = (sl.flags & SPF_COMPLEX) != 0;
+                for (uint32_t a = 0; a < i && !cut_before; ++a) cut_before = spec_reads_what(ls[a]);
+                if (cut_before) { seq0 = i == 0; if (i) { if (sl.flags & SPF_COMPLEX) par_cut_complex += 1; else par_cut_conflict += 1; } break; }
+                n_commit = i + 1; par_entries += 1;
+                if (sl.flags & SPF_FOUND) break;
+                if (wks[i].on) break;   // an extension under way: nothing is popped before it is over
+                // what this lane pushed is popped before every later entry whose (priority, state) is not below it
+                if (sl.min_child != 0xFFFFFFFFu) {
+                    uint32_t lim = i + 1;
+                    while (lim < n_off && (f << 2 | est[lim]) < sl.min_child) lim += 1;
+                    if (lim < limit) { limit = lim; }
+                }
+            }
+            if (n_commit < n_off && n_commit == limit) par_cut_leftover += 1;
+            if (seq0) {
+                // the generic code, sequentially: the rest of the extension, or the first entry
+                par_seq += 1;
+                if (w_on) found = lean_walk_generic(walk, R, end_score);
+                else {
+                    bq_drop(st0, d0, 1, prevc[st0]);
+                    const uint32_t sk = inspect_skip(ent[0].x, ent[0].y, ent[0].z, st0);
+                    if (sk == 2) num_pruned += 1;
+                    if (sk == 0 && !err) found = process_popped(ent[0].x, ent[0].y, ent[0].z, st0, R, end_score);
+                }
+                continue;
+            }
+            par_hist[n_commit] += 1; par_hist_nb[n_off] += 1;
+            // the committed entries leave their stacks (the extension under way is not one of them)
+            {
+                uint32_t left = n_commit - w_on;
+                for (uint32_t s2 = st0; have_q && s2 < 3 && left; ++s2) {
+                    const uint32_t k = taken[s2] < left ? taken[s2] : left;
+                    if (k) bq_drop_at(f, s2, ds3[s2], k, prevc[s2]);
+                    left -= k;
+                }
+            }
+            walk = wks[n_commit - 1];   // (on only if the last committed lane left its extension under way)
+            for (uint32_t i = 0; i < n_commit; ++i) {
+                spec_commit(ls[i]);
+                for (uint32_t k = 0; k < ls[i].n_p; ++k) { const ExU4 q = ls[i].p[k]; bq_push(q.w >> 2, q.w & 3u, q.x, q.y, q.z); }
+                if (ls[i].flags & SPF_FOUND) { found = true; R.end_row = rs[i].end_row; R.end_off = rs[i].end_off; end_score = es[i]; }
+            }
+        }
+        delete[] buf; delete[] ls; delete[] rs; delete[] es; delete[] ent; delete[] est; delete[] wks;
         R.status = err ? err : (found ? EX_OK : EX_PANIC);
         R.score = end_score;
         R.num_queued = num_queued; R.num_visited = num_visited; R.num_pruned = num_pruned;

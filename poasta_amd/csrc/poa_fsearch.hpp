@@ -1,25 +1,27 @@
-// Replay of the reference's search, one wavefront per query, the top entries of a stack expanded AT ONCE (exact / hybrid mode).
+// Replay of the reference's search (exact / hybrid mode): several queries per wavefront, the next entries of each query's queue
+// expanded AT ONCE, one per lane.
 //
 // The reference pops one state at a time (astar.rs:141-216) and its tie-breaks are decided by that order, so the replay has to
-// produce exactly the writes and pushes of that loop.  But the entries that sit on top of one another in a stack of the bucket
-// queue (gap_affine.rs:929-1013) rarely have anything to do with each other: on the 1 kbp reads of the benchmark a bucket holds
-// some 400 states spread over a band of the table.  A step of this kernel therefore
+// produce exactly the writes and pushes of that loop.  But the entries that follow one another in the queue's pop order (the
+// stacks of a bucket: Match, Deletion, Insertion, each from its top, gap_affine.rs:929-1013) rarely have anything to do with each
+// other: on the 1 kbp reads of the benchmark a bucket holds some 400 states spread over a band of the table.  A group of GS lanes
+// owns a query, and a step of the group
 //
-//   1. reads the top entries of the current stack, one per lane;
-//   2. lets every lane process ITS entry in the log mode of the search object (poa_exact.hpp, SpecLane): the ordinary code —
-//      stale test, pruning, greedy extension, relaxations — reading the table as the step found it (plus the lane's own log)
-//      and writing cells, reached marks and pushes to a per-lane log; entries the expansion puts in front of the next entry of
-//      the stack (same bucket, state of equal or higher pop priority) stay with the lane and are processed by it, in the
-//      queue's order;
-//   3. finds the first lane that read a cell or a reached mark an EARLIER lane of the step logged a write to (a table of lane
-//      masks in LDS, keyed by 64-cell blocks / words of the reached sets, names the candidates; the test itself is exact);
-//   4. commits the logs of the lanes before it in lane order — the writes and pushes of the sequential loop — pops their
-//      entries, and leaves the rest for the next step.  A lane that ends the search or has entries of its group left is the
-//      last one committed (what is left goes on the queue); a lane that needs what the log mode does not do takes the
-//      sequential code once it is the first lane of a step.
+//   1. reads the next entries in pop order, one per lane (the stacks of the current bucket one after the other);
+//   2. lets every lane process ITS entry in the log mode of the search object (poa_exact.hpp, SpecLane / spec_entry): the
+//      ordinary code — stale test, pruning, greedy extension, relaxations — reading the table as the step found it and writing
+//      cells, reached marks and pushes to a per-lane log;
+//   3. finds the first lane that read a cell or a reached mark an EARLIER lane of the step logged a write to (two tables in LDS
+//      keyed by independent hashes of the 64-cell block / the word of the reached set hold the lowest writing lane; a chance
+//      match only ends the step early), and the first lane that something an earlier lane pushed would be popped before;
+//   4. commits the logs of the lanes before those, in lane order — the writes and pushes of the sequential loop — pops their
+//      entries, and leaves the rest for the next step.  A lane that needs what the log mode does not do takes the sequential
+//      code once it is the first lane of a step.
 //
-// ExactSearch::run_parallel (poa_exact.hpp) is this schedule one lane after the other; compiled for the host it is diffed
-// against the oracle (tests/test_exact_replay.py), this kernel against both on the GPU.
+// No lane ever works through a chain of entries alone (an entry's children are ordinary entries of a later step), and the
+// groups of a wave step through one instruction stream: that is what keeps the lanes of an instruction busy.
+// ExactSearch::run_flat (poa_exact.hpp) is this schedule one lane after the other; compiled for the host it is diffed against
+// the oracle (tests/test_exact_replay.py), this kernel against both on the GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,17 +32,18 @@ namespace poa_amd {
 constexpr uint32_t PS_TAB = 512;       // slots of each of the two conflict tables (lowest writing lane per key), per wave
 constexpr uint32_t PS_TAB_BITS = 9;
 
-struct PSearchParams {
+struct FSearchParams {
     ExactParams E;            // graph, queries, planes, reached sets, costs, status / end cell
     ExU4* chunks;             // per slot: chunk_cap chunks of BQ_CHUNK slots
     uint32_t chunk_cap;
     uint32_t win;             // descriptor ring: priorities per wave (power of two)
     uint32_t* ring_global;    // null: the rings live in LDS; else [slots * 3 * win] in global memory
     uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
+    uint32_t rec_lds;         // bytes of the staged row records (lean step), 0: none staged
+    uint32_t lean;            // 1: the lean step (needs E.G.rec), 0: the generic code in log mode
     uint32_t waves_per_block;
-    uint32_t group;           // lanes per query: 64 (one query per wave), 32 or 16
-    uint32_t max_lanes;       // entries per step (<= group - 1)
-    uint32_t rmax;            // entries a lane may process per step (its own and what they push in front of the next)
+    uint32_t group;           // lanes per query: 64 (one query per wave), 16, 8 or 4
+    uint32_t max_lanes;       // entries per step (<= group)
     uint32_t* scratch;        // per slot: ps_scratch_words() words — the lanes' push logs and extension stacks
     uint32_t* work_counter;   // persistent scheduling (see poa_wsearch.hpp); null: query = block / wave index
     const uint32_t* order;
@@ -72,24 +75,52 @@ __device__ __forceinline__ uint32_t ps_key2(uint32_t k) { return PS_TAB + ((k * 
 __device__ __forceinline__ uint32_t ps_mark_id(uint32_t x, uint32_t word) { return 0x80000000u | (x * 0x3D4D51CBu + word * 0xC2B2AE35u); }
 constexpr uint32_t PS_ALL_WORDS = 0xFFFFFFu;   // "some word of this exit's set": key of a range too wide to name its words
 
-template <int AS, int GS>
-__device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGraph& G, uint8_t* wbase, uint32_t lane, uint32_t wave);
+// The generic code for one entry (or the rest of a greedy extension) — direct mode, one lane, sequential.  It is a function of
+// its own, working on a copy of the search's state in memory, so that the step kernel keeps its registers for the step: a lane
+// comes here for a row in a thousand.
+struct FsFallbackIO {
+    ExactGraph G; ExactWork W; const uint8_t* seq; uint32_t L; ExactCosts C;
+    uint32_t layer_min, bq_live, bq_hi, bq_chunk_top, bq_free, err;     // queue state, in / out
+    uint32_t walk_on; ExactSearchT<0>::LeanWalk wk; ExU4 e; uint32_t st;  // what: the extension wk, or the entry e of state st
+    uint32_t found, end_score, end_row, end_off, dq, dv, dp;              // out: end of the search; counters to add
+};
+__device__ __attribute__((noinline)) void fs_fallback(FsFallbackIO* io) {
+    ExactSearchT<0> S(io->G, io->W, io->seq, io->L, io->C);
+    S.layer_min = io->layer_min; S.bq_live = io->bq_live; S.bq_hi = io->bq_hi; S.bq_chunk_top = io->bq_chunk_top; S.bq_free = io->bq_free;
+    S.err = io->err; S.bq_wr = true;
+    ExactResult R{EX_OK, EX_INF, 0, 0, 0, io->G.end_row, io->L};
+    uint32_t end_score = EX_INF;
+    bool found = false;
+    if (io->walk_on) found = S.lean_walk_generic(io->wk, R, end_score);
+    else {
+        const uint32_t sk = S.inspect_skip(io->e.x, io->e.y, io->e.z, io->st);
+        if (sk == 2) S.num_pruned += 1;
+        if (sk == 0 && !S.err) found = S.process_popped(io->e.x, io->e.y, io->e.z, io->st, R, end_score);
+    }
+    io->layer_min = S.layer_min; io->bq_live = S.bq_live; io->bq_hi = S.bq_hi; io->bq_chunk_top = S.bq_chunk_top; io->bq_free = S.bq_free; io->err = S.err;
+    io->found = found ? 1u : 0u; io->end_score = end_score; io->end_row = R.end_row; io->end_off = R.end_off;
+    io->dq = S.num_queued; io->dv = S.num_visited; io->dp = S.num_pruned;
+}
 
-__global__ __launch_bounds__(512) void poa_psearch_kernel(PSearchParams P) {
+template <int AS, int GS, bool LEAN>
+__device__ __forceinline__ void fs_search(const FSearchParams& P, const ExactGraph& G, uint8_t* wbase, uint32_t lane, uint32_t wave);
+
+template <bool LEAN>
+__device__ __forceinline__ void fs_kernel_body(const FSearchParams& P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const ExactParams& E = P.E;
     ExactGraph G = E.G;
     const uint32_t nthreads = blockDim.x;
+    uint32_t at = 0;
+    auto stage = [&](const void* src, uint64_t bytes) {
+        uint8_t* dst = lds + at;
+        const uint32_t words = (uint32_t)((bytes + 3) / 4);
+        const uint32_t* s32 = static_cast<const uint32_t*>(src);
+        for (uint32_t i = threadIdx.x; i < words; i += nthreads) reinterpret_cast<uint32_t*>(dst)[i] = s32[i];
+        at += (uint32_t)((bytes + 15) & ~15ull);
+        return dst;
+    };
     if (P.graph_lds) {
-        uint32_t at = 0;
-        auto stage = [&](const void* src, uint64_t bytes) {
-            uint8_t* dst = lds + at;
-            const uint32_t words = (uint32_t)((bytes + 3) / 4);
-            const uint32_t* s32 = static_cast<const uint32_t*>(src);
-            for (uint32_t i = threadIdx.x; i < words; i += nthreads) reinterpret_cast<uint32_t*>(dst)[i] = s32[i];
-            at += (uint32_t)((bytes + 15) & ~15ull);
-            return dst;
-        };
         const uint32_t n = E.G.n_rows;
         G.sym = stage(E.G.sym, n);
         G.succ_off = reinterpret_cast<const uint32_t*>(stage(E.G.succ_off, 4ull * (n + 1)));
@@ -100,30 +131,34 @@ __global__ __launch_bounds__(512) void poa_psearch_kernel(PSearchParams P) {
         G.exit_idx = reinterpret_cast<const uint32_t*>(stage(E.G.exit_idx, 4ull * n));
         G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(E.G.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)E.n_nbm));
     }
+    if (P.rec_lds) G.rec = reinterpret_cast<const FlatGraph::RowRec*>(stage(E.G.rec, sizeof(FlatGraph::RowRec) * (uint64_t)E.G.n_rows));
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // per wave: [descriptor rings of its queries (unless global)] [conflict tables | logs | read sets | push map]
     const uint32_t qpw = 64u / P.group;
     const uint32_t ring_bytes = P.ring_global ? 0u : ((qpw * 3u * P.win * 4u + 15u) & ~15u);
-    uint8_t* wbase = lds + P.graph_lds + (uint64_t)wave * (ring_bytes + ps_lds_bytes());
+    uint8_t* wbase = lds + P.graph_lds + P.rec_lds + (uint64_t)wave * (ring_bytes + ps_lds_bytes());
     __syncthreads();
-    // graph arrays and rings both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers for those two
-    const bool lds_all = P.graph_lds && !P.ring_global;
-    if (P.group == 64) {
-        if (lds_all) ps_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, 64>(P, G, wbase, lane, wave);
-        else ps_search<EX_AS_READSET_LDS, 64>(P, G, wbase, lane, wave);
-    } else if (P.group == 32) {
-        if (lds_all) ps_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, 32>(P, G, wbase, lane, wave);
-        else ps_search<EX_AS_READSET_LDS, 32>(P, G, wbase, lane, wave);
-    } else {
-        if (lds_all) ps_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, 16>(P, G, wbase, lane, wave);
-        else ps_search<EX_AS_READSET_LDS, 16>(P, G, wbase, lane, wave);
-    }
+    // what is staged in LDS is read through typed LDS accesses (a pointer that may be global or LDS compiles to FLAT loads)
+    const bool lds_ring = !P.ring_global;
+#define FS_CALL(GS_) do { \
+        if constexpr (LEAN) { \
+            if (P.rec_lds && lds_ring) fs_search<EX_AS_REC_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, GS_, true>(P, G, wbase, lane, wave); \
+            else fs_search<EX_AS_READSET_LDS, GS_, true>(P, G, wbase, lane, wave); \
+        } else { \
+            if (P.graph_lds && lds_ring) fs_search<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_READSET_LDS, GS_, false>(P, G, wbase, lane, wave); \
+            else fs_search<EX_AS_READSET_LDS, GS_, false>(P, G, wbase, lane, wave); \
+        } } while (0)
+    // (group sizes built: 8 lanes per query for the lean step, 16 for the generic code in log mode — the engine asks for these)
+    if constexpr (LEAN) FS_CALL(8); else FS_CALL(16);
+#undef FS_CALL
 }
+__global__ __launch_bounds__(512) void poa_fsearch_kernel(FSearchParams P) { fs_kernel_body<false>(P); }        // generic code in log mode
+__global__ __launch_bounds__(512) void poa_fsearch_lean_kernel(FSearchParams P) { fs_kernel_body<true>(P); }    // the lean step
 
 // GS lanes per query, 64 / GS queries per wave, all stepping through one instruction stream: what is uniform over a wave with one
 // query (queue state, the cut of a step) is uniform over a group here and travels by shuffles inside the group.
-template <int AS, int GS>
-__device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGraph& G, uint8_t* wbase, uint32_t lane, uint32_t wave) {
+template <int AS, int GS, bool LEAN>
+__device__ __forceinline__ void fs_search(const FSearchParams& P, const ExactGraph& G, uint8_t* wbase, uint32_t lane, uint32_t wave) {
     const ExactParams& E = P.E;
     constexpr uint32_t QPW = 64u / GS;
     const uint32_t grp = lane / GS, gl = lane % GS, gbase = grp * GS;
@@ -174,6 +209,7 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
     S.sl.dstack = reinterpret_cast<ExStackEntry*>(sc + 64u * 4 * SP_KP) + lane;
     ExactResult R{EX_OK, EX_INF, 0, 0, 0, G.end_row, 0};
     uint32_t end_score = EX_INF, found = 0, steps = 0, qi = 0;
+    typename ExactSearchT<AS>::LeanWalk wk;   // the greedy extension under way (lean step), group-uniform
     bool have = false, more = slot < E.n_queries, first = true;   // (the workspace has a slot per query of the chunk at least)
 
     // group-uniform state lives identically in every lane of the group; what one lane changes alone is handed round afterwards
@@ -188,6 +224,13 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
         end_score = gsh(end_score, from);
         R.end_row = gsh(R.end_row, from);
         R.end_off = gsh(R.end_off, from);
+    };
+    auto adopt_walk = [&](const typename ExactSearchT<AS>::LeanWalk& w, uint32_t from) {
+        wk.on = gsh(w.on, from); wk.r = gsh(w.r, from); wk.j = gsh(w.j, from); wk.k = gsh(w.k, from); wk.g = gsh(w.g, from);
+        wk.iopen = gsh(w.iopen, from); wk.sib_n = gsh(w.sib_n, from); wk.dv = gsh(w.dv, from);
+        wk.sib_r[0] = gsh(w.sib_r[0], from); wk.sib_r[1] = gsh(w.sib_r[1], from);
+        wk.sib_j[0] = gsh(w.sib_j[0], from); wk.sib_j[1] = gsh(w.sib_j[1], from);
+        wk.sib_io[0] = gsh(w.sib_io[0], from); wk.sib_io[1] = gsh(w.sib_io[1], from);
     };
 
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -223,6 +266,7 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
                         S.begin_query(E.qseq + qbeg, (uint32_t)(E.qoff[qi + 1] - qbeg));
                         R = ExactResult{EX_OK, EX_INF, 0, 0, 0, G.end_row, S.L};
                         end_score = EX_INF; found = 0; steps = 0;
+                        wk = typename ExactSearchT<AS>::LeanWalk();
                         have = true;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         S.bq_wr = true;
@@ -238,17 +282,46 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
 
         // ---- one step of every group that has a search ----
         const bool go = have && !found && !S.err;
-        uint32_t st = 0; BqDesc d{0, 0};
-        if (go && !S.bq_current(st, d)) S.err = EX_PANIC;   // "Could not align sequence!" (astar.rs:142-144)
+        const uint32_t w_on = (go && wk.on) ? 1u : 0u;        // an extension is under way: the group's first lane goes on with it
+        uint32_t st0 = 0; BqDesc d0{0, 0};
+        bool have_q = false;
+        if (go) { have_q = S.bq_current(st0, d0); if (!have_q && !w_on) S.err = EX_PANIC; }   // "Could not align sequence!" (astar.rs:142-144)
         const bool run = go && !S.err;
         const uint32_t f = S.layer_min;
-        const uint32_t cap = P.max_lanes < (uint32_t)(GS - 1) ? P.max_lanes : (uint32_t)(GS - 1);
-        const uint32_t nb = run ? (d.n_top < cap ? d.n_top : cap) : 0u;   // the top chunk's entries: lane i of the group takes the i-th from the top
-        const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
-        const bool act = gl < nb;
+        const uint32_t cap = P.max_lanes < (uint32_t)GS ? P.max_lanes : (uint32_t)GS;
+        // the stacks of bucket f from st0 on: how many entries each offers (its top chunk), in pop order
+        uint32_t dsw[3] = {BQ_EMPTY, BQ_EMPTY, BQ_EMPTY}, cnt3[3] = {0, 0, 0}, beg3[3] = {w_on, w_on, w_on};   // beg3: first lane of a state's entries
+        if (run && have_q) {
+            uint32_t* b3 = &W.bq_desc[3 * (f & (W.bq_win - 1))];
+#pragma unroll
+            for (uint32_t s2 = 0; s2 < 3; ++s2) { const uint32_t dw = S.rld(b3 + s2); dsw[s2] = dw; cnt3[s2] = (s2 >= st0 && dw != BQ_EMPTY) ? (dw & 63u) : 0u; }
+            beg3[1] = w_on + cnt3[0]; beg3[2] = w_on + cnt3[0] + cnt3[1];
+        }
+        // lane gl: which stack, which entry from its top
+        uint32_t lst = 0, lidx = gl - w_on;
+        if (gl >= beg3[1]) { lst = 1; lidx = gl - beg3[1]; }
+        if (gl >= beg3[2]) { lst = 2; lidx = gl - beg3[2]; }
+        const uint32_t ltop = lst == 0 ? (dsw[0] >> 6) : lst == 1 ? (dsw[1] >> 6) : (dsw[2] >> 6);
+        const uint32_t lcnt = lst == 0 ? cnt3[0] : lst == 1 ? cnt3[1] : cnt3[2];
+        bool act = run && gl >= w_on && gl < cap && lidx < lcnt;
         ExU4 e{0, 0, 0, 0};
-        if (run) e = ch[act ? d.n_top - gl : 0];             // the idle lanes read slot 0: {previous chunk}
-        const uint32_t prev = gsh(e.x, GS - 1);               // (the last lane of a group is never active)
+        uint32_t lprev = EX_NIL;
+        if (act) {
+            const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * ltop;
+            e = ch[lcnt - lidx];
+            lprev = ch[0].x;   // {previous chunk} of that stack
+        }
+        // a stack is left for the next one only when it was taken whole: the lanes of the stacks behind one that has more to
+        // offer (entries beyond the cap, or an earlier chunk) do not take part
+        const uint32_t pv0 = gsh(lprev, beg3[0] < GS ? beg3[0] : 0), pv1 = gsh(lprev, beg3[1] < GS ? beg3[1] : 0), pv2 = gsh(lprev, beg3[2] < GS ? beg3[2] : 0);
+        {
+            const bool more0 = cnt3[0] != 0 && (beg3[1] > cap || pv0 != EX_NIL);
+            const bool more1 = cnt3[1] != 0 && (beg3[2] > cap || pv1 != EX_NIL);
+            if (lst >= 1 && more0) act = false;
+            if (lst >= 2 && (more0 || more1)) act = false;
+        }
+        if (run && w_on && gl == 0) act = true;   // (the extension under way)
+        const uint32_t n_off = (uint32_t)__builtin_popcountll(gballot(act));   // (the active lanes are the first n_off of the group)
         // the conflict tables of this step (4 KB: 8 bytes per lane, eight times)
         {
             lds_u64* t8 = (lds_u64*)wlds;
@@ -257,10 +330,12 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
         }
         if (run) steps += 1;
         PS_TICK(0);
-        // ---- every lane: its entry (and what that puts in front of the next one) in log mode ----
+        // ---- every lane: its entry in log mode ----
         ExactResult Rl = R; uint32_t esl = end_score;
-        S.sl.flags = 0; S.sl.n_w = S.sl.n_m = S.sl.n_p = S.sl.n_pd = S.sl.n_rc = S.sl.n_rm = 0; S.sl.n_ent = 0;
-        if (act) S.spec_group(e.x, e.y, e.z, st, f, P.rmax, Rl, esl);
+        S.sl.flags = 0; S.sl.n_w = S.sl.n_m = S.sl.n_p = S.sl.n_pd = S.sl.n_rc = S.sl.n_rm = 0; S.sl.n_ent = 0; S.sl.min_child = 0xFFFFFFFFu;
+        typename ExactSearchT<AS>::LeanWalk wl = wk;
+        if (!(w_on && gl == 0)) wl = typename ExactSearchT<AS>::LeanWalk();
+        if (act) { if constexpr (LEAN) S.spec_lean(e.x, e.y, e.z, lst, wl); else S.spec_entry(e.x, e.y, e.z, lst, Rl, esl); }
         PS_TICK(1);
         // ---- who read what an earlier lane wrote ----
         // Writers enter their lane (lowest wins) under two independent hashes of every cell they logged / every word of a
@@ -304,43 +379,73 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
         }
         PS_TICK(2);
         // ---- how many lanes of the group commit ----
+        // (a) before the first lane that clashes or needs the sequential code; through the first one that ends the search;
         const unsigned long long m_cx = gballot(act && (clash || (S.sl.flags & SPF_COMPLEX)));
-        const unsigned long long m_last = gballot(act && (S.sl.flags & (SPF_FOUND | SPF_LEFTOVER)));
-        uint32_t n_commit = m_cx ? (uint32_t)__builtin_ctzll(m_cx) : nb;
-        if (m_last) { const uint32_t a = (uint32_t)__builtin_ctzll(m_last) + 1; n_commit = a < n_commit ? a : n_commit; }
+        const unsigned long long m_fd = gballot(act && (S.sl.flags & SPF_FOUND));
+        uint32_t n_commit = m_cx ? (uint32_t)__builtin_ctzll(m_cx) : n_off;
+        if (m_fd) { const uint32_t a = (uint32_t)__builtin_ctzll(m_fd) + 1; n_commit = a < n_commit ? a : n_commit; }
+        {   // through the first one that leaves an extension under way: nothing is popped before that is over
+            const unsigned long long m_wk = gballot(act && wl.on != 0);
+            if (m_wk) { const uint32_t a = (uint32_t)__builtin_ctzll(m_wk) + 1; n_commit = a < n_commit ? a : n_commit; }
+        }
+        // (b) what a committed lane pushed is popped before every later entry whose (priority, state) is not below it: the first
+        //     such lane ends the step.  The lanes' keys are (f, state) with the states in order, so that lane is where the
+        //     child's state begins among the lanes (or the very next lane).
+        {
+            const uint32_t mc = S.sl.min_child;
+            uint32_t lim = n_off;
+            if (act && mc != 0xFFFFFFFFu) {
+                if (mc <= (f << 2 | 0u)) lim = gl + 1;
+                else if (mc <= (f << 2 | 1u)) lim = beg3[1] > gl + 1 ? beg3[1] : gl + 1;
+                else if (mc <= (f << 2 | 2u)) lim = beg3[2] > gl + 1 ? beg3[2] : gl + 1;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i + 1 < (uint32_t)GS; ++i) {   // lane i's limit counts once lane i itself commits
+                const uint32_t li = gsh(lim, i);
+                if (i < n_commit && li < n_commit) n_commit = li;
+            }
+        }
         const bool seq = run && n_commit == 0;   // the group's first lane needs the sequential code (direct mode): its entry alone
         if (__any(seq)) {
             if (seq) {
-                S.bq_drop(st, d, 1, prev);
+                if (!w_on) S.bq_drop(st0, d0, 1, pv0);
                 if (gl == 0) {
-                    S.bq_wr = true;
-                    const uint32_t sk = S.inspect_skip(e.x, e.y, e.z, st);
-                    if (sk == 2) S.num_pruned += 1;
-                    if (sk == 0 && !S.err) found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+                    FsFallbackIO io;
+                    io.G = P.E.G; io.W = W; io.seq = S.seq; io.L = S.L; io.C = S.C;
+                    io.layer_min = S.layer_min; io.bq_live = S.bq_live; io.bq_hi = S.bq_hi; io.bq_chunk_top = S.bq_chunk_top; io.bq_free = S.bq_free; io.err = S.err;
+                    io.walk_on = w_on;
+                    io.wk.on = wk.on; io.wk.r = wk.r; io.wk.j = wk.j; io.wk.k = wk.k; io.wk.g = wk.g; io.wk.iopen = wk.iopen; io.wk.sib_n = wk.sib_n; io.wk.dv = wk.dv;
+                    io.wk.sib_r[0] = wk.sib_r[0]; io.wk.sib_r[1] = wk.sib_r[1]; io.wk.sib_j[0] = wk.sib_j[0]; io.wk.sib_j[1] = wk.sib_j[1]; io.wk.sib_io[0] = wk.sib_io[0]; io.wk.sib_io[1] = wk.sib_io[1];
+                    io.e = e; io.st = st0;
+                    fs_fallback(&io);
+                    S.layer_min = io.layer_min; S.bq_live = io.bq_live; S.bq_hi = io.bq_hi; S.bq_chunk_top = io.bq_chunk_top; S.bq_free = io.bq_free; S.err = io.err;
+                    S.num_queued += io.dq; S.num_visited += io.dv; S.num_pruned += io.dp;
+                    if (io.found) { found = 1; end_score = io.end_score; R.end_row = io.end_row; R.end_off = io.end_off; }
+                    wk.on = 0; wk.sib_n = 0; wk.dv = 0;
                 }
             }
             S.bq_wr = gl == 0;
             adopt(0);
+            adopt_walk(wk, 0);
             PS_TICK(4);
             if (prof && seq) pc[6] += 1;
         }
         const bool com = run && n_commit != 0;
-        // ---- commit: table, marks, counters of the lanes before the cut; their entries leave the stack ----
+        // ---- commit: table, marks, counters of the lanes before the cut; their entries leave their stacks ----
         if (com && gl < n_commit) S.spec_commit(S.sl);
-        if (com) S.bq_drop(st, d, n_commit, prev);
-        // what the last lane left pending goes on the queue in its push order
-        const uint32_t last = com ? n_commit - 1 : 0u;
-        const uint32_t npd = gsh(S.sl.n_pd, last);
-        if (__any(com && npd != 0)) {
-            if (com && npd && gl == last) {
-                S.bq_wr = true;
-                if (S.sl.n_pd > 0) S.bq_push(S.sl.pd_key[0] >> 2, S.sl.pd_key[0] & 3u, S.sl.pd_score[0], S.sl.pd_row[0], S.sl.pd_off[0]);
-                if (S.sl.n_pd > 1) S.bq_push(S.sl.pd_key[1] >> 2, S.sl.pd_key[1] & 3u, S.sl.pd_score[1], S.sl.pd_row[1], S.sl.pd_off[1]);
-                if (S.sl.n_pd > 2) S.bq_push(S.sl.pd_key[2] >> 2, S.sl.pd_key[2] & 3u, S.sl.pd_score[2], S.sl.pd_row[2], S.sl.pd_off[2]);
-                if (S.sl.n_pd > 3) S.bq_push(S.sl.pd_key[3] >> 2, S.sl.pd_key[3] & 3u, S.sl.pd_score[3], S.sl.pd_row[3], S.sl.pd_off[3]);
+        if (com) {
+#pragma unroll
+            for (uint32_t s2 = 0; s2 < 3; ++s2) {
+                const uint32_t hi = beg3[s2] + cnt3[s2] < n_commit ? beg3[s2] + cnt3[s2] : n_commit;   // (lanes [beg3, beg3 + cnt3) hold this stack's entries)
+                const uint32_t k = hi > beg3[s2] ? hi - beg3[s2] : 0u;
+                if (k) S.bq_drop_at(f, s2, BqDesc{dsw[s2] >> 6, dsw[s2] & 63u}, k, s2 == 0 ? pv0 : s2 == 1 ? pv1 : pv2);
             }
-            S.bq_wr = gl == 0;
-            adopt((com && npd) ? last : 0u);
+        }
+        const uint32_t last = com ? n_commit - 1 : 0u;
+        {   // the extension the last committed lane left under way (or none) is the group's from here on
+            typename ExactSearchT<AS>::LeanWalk keep = wk;
+            adopt_walk(wl, last);
+            if (!com) wk = keep;
         }
         PS_TICK(3);
         // ---- the logged pushes, in the order the sequential loop makes them: lane after lane, each lane's in its own order ----
@@ -407,7 +512,7 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
         {
             const uint32_t fl = gsh(S.sl.flags, last);
             const uint32_t es2 = gsh(esl, last), er = gsh(Rl.end_row, last), eo = gsh(Rl.end_off, last);
-            if (com && m_last && (uint32_t)__builtin_ctzll(m_last) == last && (fl & SPF_FOUND)) { found = 1; end_score = es2; R.end_row = er; R.end_off = eo; }
+            if (com && (fl & SPF_FOUND)) { found = 1; end_score = es2; R.end_row = er; R.end_off = eo; }
         }
         PS_TICK(5);
         if (prof && com) pc[7] += n_commit;
@@ -435,6 +540,9 @@ __device__ __forceinline__ void ps_search(const PSearchParams& P, const ExactGra
             if (fin) {
                 have = false; S.num_queued = S.num_visited = S.num_pruned = 0;
                 for (int k = 0; k < 8; ++k) pc[k] = 0;
+#if defined(POA_PS_PROF_FINE)
+                for (int k = 0; k < 8; ++k) S.pf[k] = 0;
+#endif
             }
         }
     }

@@ -357,6 +357,37 @@ int build_bubble_index(FlatGraph& g, std::string& err) {
     g.exit_idx.assign(n, 0xFFFFFFFFu);
     g.n_exit = 0;
     for (uint32_t r = 0; r < n; ++r) if (g.is_exit[r]) g.exit_idx[r] = g.n_exit++;
+    // the per-row records of the replay's step
+    g.row_rec.clear();
+    if (n < 0xFFFFu) {
+        g.row_rec.resize(n);
+        for (uint32_t r = 0; r < n; ++r) {
+            FlatGraph::RowRec rr{};
+            rr.c0 = rr.c1 = rr.e0 = rr.e1 = 0xFFFFu; rr.x0 = rr.x1 = 0xFFFFu;
+            const uint32_t s0 = g.succ_row_off[r], ns = g.succ_row_off[r + 1] - s0;
+            uint8_t fl = r == g.end_row ? FlatGraph::RR_END : 0;
+            rr.sym = g.rows[r].sym;
+            if (ns >= 1) { rr.c0 = (uint16_t)g.succ_rows[s0]; rr.sym0 = g.rows[g.succ_rows[s0]].sym; }
+            if (ns >= 2) { rr.c1 = (uint16_t)g.succ_rows[s0 + 1]; rr.sym1 = g.rows[g.succ_rows[s0 + 1]].sym; }
+            if ((ns == 1 || ns == 2) && g.succ_rows[s0] != g.end_row && (ns == 1 || g.succ_rows[s0 + 1] != g.end_row)) fl |= FlatGraph::RR_SUCC_OK;
+            if (ns == 2) fl |= FlatGraph::RR_HAS_C1;
+            bool pok = true; uint32_t nb = 0;
+            for (uint32_t k = g.nbm_off[r]; k < g.nbm_off[r + 1]; ++k) {
+                const FlatGraph::NodeBubble& b = g.nbm[k];
+                if (b.exit_row == r) continue;                  // reached.rs:56-58: the bubble the row exits is never tested
+                const uint32_t md = g.dist_min[b.exit_row] ? g.dist_min[b.exit_row] - 1 : 0;
+                if (nb == 2 || b.max_dist > 255 || b.min_dist > b.max_dist || b.max_dist - b.min_dist > 2 || md > 0xFFFFu) { pok = false; break; }
+                if (nb == 0) { rr.e0 = (uint16_t)b.exit_row; rr.x0 = (uint16_t)g.exit_idx[b.exit_row]; rr.d0min = (uint8_t)b.min_dist; rr.d0max = (uint8_t)b.max_dist; rr.mde0 = (uint16_t)md; }
+                else { rr.e1 = (uint16_t)b.exit_row; rr.x1 = (uint16_t)g.exit_idx[b.exit_row]; rr.d1min = (uint8_t)b.min_dist; rr.d1max = (uint8_t)b.max_dist; rr.mde1 = (uint16_t)md; }
+                nb += 1;
+            }
+            if (pok) fl |= FlatGraph::RR_PROBE_OK;
+            const uint32_t dn = g.dist_min[r] ? g.dist_min[r] - 1 : 0, dx = g.dist_max[r] ? g.dist_max[r] - 1 : 0;
+            rr.dmin = (uint16_t)dn; rr.dmax = (uint16_t)dx;   // (< 65535: at most n - 1)
+            rr.flags = fl;
+            g.row_rec[r] = rr;
+        }
+    }
     g.bubbles_built = true;
     return POA_OK;
 }

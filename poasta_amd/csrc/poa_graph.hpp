@@ -105,6 +105,25 @@ struct FlatGraph {
     struct NodeBubble { uint32_t exit_row, min_dist, max_dist; };
     std::vector<uint32_t> nbm_off;                // [n+1]
     std::vector<NodeBubble> nbm;                  // node_bubble_map flattened, per-node order preserved
+    // Everything the replay's step reads of a row, in one 32-byte record (graphs of fewer than 65535 rows): successors, the
+    // (up to two) bubbles it lies in besides the one it exits — exit row, its index among the exits, the distances to it —
+    // the row's own distances to the end (what the min-gap heuristic reads, heuristic.rs:70-102, already minus one) and the
+    // symbols.  flags says which parts hold the whole truth; a row that has more takes the generic code.
+    struct RowRec {
+        uint16_t c0, c1;             // successor rows in trait order (0xFFFF: none)
+        uint16_t e0, e1;             // exit rows of the bubbles (node_bubble_map order; 0xFFFF: none)
+        uint16_t x0, x1;             // their indices among the exit rows
+        uint8_t d0min, d0max, d1min, d1max;
+        uint16_t dmin, dmax;         // max(dist_to_end - 1, 0), (min, max)
+        uint16_t mde0, mde1;         // max(dist_min[exit] - 1, 0)
+        uint8_t sym, sym0, sym1, flags;
+        uint32_t pad;
+    };
+    enum : uint8_t { RR_SUCC_OK = 1,   // one or two successors, neither the end row; c0 / c1 / sym0 / sym1 say all
+                     RR_HAS_C1 = 2,
+                     RR_PROBE_OK = 4,  // at most two such bubbles, distances below 256 and at most two apart
+                     RR_END = 8 };
+    std::vector<RowRec> row_rec;                  // empty: the graph has too many rows for 16-bit fields
     bool bubbles_built = false;
 };
 
@@ -112,6 +131,7 @@ struct FlatGraph {
 // and rev_postorder_nodes (src/graphs/tools.rs:5-37).  Needed only by the exact-replay mode: it steers
 // the reference's heuristic and pruning and therefore which cells its search visits.
 int build_bubble_index(FlatGraph& g, std::string& err);
+static_assert(sizeof(FlatGraph::RowRec) == 32, "RowRec layout");
 
 // Returns POA_OK or POA_ERR_*; `err` receives a description.
 int build_flat_graph(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol,

@@ -14,7 +14,7 @@
 
 using namespace poa_amd;
 
-static uint32_t g_batch = 0, g_win = 0, g_par_lanes = 0, g_par_rmax = 4, g_par_fast = 1;
+static uint32_t g_batch = 0, g_win = 0, g_par_lanes = 0, g_par_rmax = 4, g_par_fast = 1;   // g_par_rmax == 0: the flat schedule (run_flat)
 
 extern "C" {
 
@@ -40,7 +40,7 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     for (uint32_t r = 0; r < g.n; ++r) row_sym[r] = g.rows[r].sym;
     ExactGraph G{g.n, g.start_row, g.end_row, row_sym.data(), g.succ_row_off.data(), g.succ_rows.data(),
                  g.dist_min.data(), g.dist_max.data(), g.exit_idx.data(), g.n_exit, g.nbm_off.data(), g.nbm.data(),
-                 g.node_row.data(), g.sp_to_end.data()};
+                 g.node_row.data(), g.sp_to_end.data(), g.row_rec.empty() ? nullptr : g.row_rec.data()};
     const uint32_t pitch = ((len + 1 + 63) / 64) * 64, wpn = (len + 1 + 63) / 64, swpn = (wpn + 63) / 64;  // as the engine lays it out
     std::vector<uint32_t> T((size_t)3 * n * pitch, EX_INF);  // tiled: ex_cell_index
     std::vector<uint64_t> reached((size_t)g.n_exit * wpn + 1, 0), rsum((size_t)g.n_exit * swpn + 1, 0);
@@ -65,7 +65,7 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     ExactCosts EC{x, o, e, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0};
     if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
     ExactSearch S(G, W, seq, len, EC);
-    ExactResult R = g_par_lanes ? S.run_parallel(g_par_lanes, g_par_rmax, g_par_fast != 0) : g_batch ? S.run_buckets(g_batch) : S.run();
+    ExactResult R = g_par_lanes ? (g_par_rmax ? S.run_parallel(g_par_lanes, g_par_rmax, g_par_fast != 0) : S.run_flat(g_par_lanes, g_par_fast != 0, g_par_fast == 2)) : g_batch ? S.run_buckets(g_batch) : S.run();
     if (getenv("EXH_VERBOSE")) fprintf(stderr, "chunks used %u of %u, status %u, fast-path tests %u, queued %u\n", S.bq_chunk_top, W.bq_chunk_cap, R.status, S.n_fast, R.num_queued);
     if (getenv("EXH_VERBOSE") && g_par_lanes) {
         fprintf(stderr, "  lanes committed per step:"); for (int k = 0; k < 65; ++k) if (S.par_hist[k]) fprintf(stderr, " %d:%u", k, S.par_hist[k]); fprintf(stderr, "\n");
@@ -76,9 +76,13 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
         fprintf(stderr, "parallel schedule: %u steps (%u sequential), %u entries in log mode; cuts: %u complex, %u conflict, %u leftover; visited %u pruned %u\n",
                 S.par_steps, S.par_seq, S.par_entries, S.par_cut_complex, S.par_cut_conflict, S.par_cut_leftover, R.num_visited, R.num_pruned);
 #if defined(POA_EXACT_DIAG)
+    if (getenv("EXH_VERBOSE")) {
+        fprintf(stderr, "  probe neighbour below t at distance 1/2/3-4/5-8/>8/none: %u %u %u %u %u %u; above: %u %u %u %u %u %u\n", S.pd_hist[0][1], S.pd_hist[0][2], S.pd_hist[0][4], S.pd_hist[0][5], S.pd_hist[0][6], S.pd_hist[0][7],
+                S.pd_hist[1][1], S.pd_hist[1][2], S.pd_hist[1][4], S.pd_hist[1][5], S.pd_hist[1][6], S.pd_hist[1][7]);
+    }
     if (getenv("EXH_VERBOSE") && g_par_lanes) {
-        fprintf(stderr, "  why complex: read cells %u, mark ranges %u, cell writes %u, marks %u, pushes %u, pending %u, dfa stack %u, prio %u\n", S.why_complex[1], S.why_complex[2],
-                S.why_complex[3], S.why_complex[4], S.why_complex[5], S.why_complex[6], S.why_complex[7], S.why_complex[9]);
+        fprintf(stderr, "  why complex: read cells %u, mark ranges %u, cell writes %u, marks %u, pushes %u, pending %u, dfa stack %u, prio %u, shape %u\n", S.why_complex[1], S.why_complex[2],
+                S.why_complex[3], S.why_complex[4], S.why_complex[5], S.why_complex[6], S.why_complex[7], S.why_complex[9], S.why_complex[10]);
     }
     if (getenv("EXH_VERBOSE")) {
         const char* why[8] = {"stale/pruned on the fast path", "several successors", "end row / misc", "bubble shape", "Match special", "probe undecided", "fast expand", "fast greedy walk"};

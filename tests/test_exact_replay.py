@@ -36,13 +36,15 @@ def harness():
     return X
 
 
-@pytest.fixture(params=[0, 1, 7, 64, (63, 4, 1), (5, 1, 1), (63, 8, 0), (2, 3, 1)],
+@pytest.fixture(params=[0, 1, 7, 64, (63, 4, 1), (5, 1, 1), (63, 8, 0), (8, 0, 1), (8, 0, 2), (63, 0, 2), (3, 0, 2), (16, 0, 0)],
                 ids=["linked_list_queue", "buckets_batch1", "buckets_batch7", "buckets_batch64", "parallel_63x4", "parallel_5x1",
-                     "parallel_63x8_generic_code", "parallel_2x3"])
+                     "parallel_63x8_generic_code", "flat_8", "flat_8_lean", "flat_63_lean", "flat_3_lean", "flat_16_generic_code"])
 def queue_variant(request, harness):
     """0: ExactSearch::run (linked-list queue, the one-search-per-lane kernel); n: ExactSearch::run_buckets(n), the
     step schedule of the wave-per-query kernel (poa_wsearch.hpp) over the bucket queue; (lanes, rmax, fast):
-    ExactSearch::run_parallel, the schedule of poa_psearch.hpp (the top entries of a stack expanded at once in log mode)."""
+    ExactSearch::run_parallel (rmax > 0: the top entries of a stack expanded at once in log mode, each lane following what its
+    entry puts in front of the next) or ExactSearch::run_flat (rmax == 0: the schedule of poa_fsearch.hpp — the next entries in
+    pop order, one per lane; fast == 2: the lean step, greedy extensions resumed from step to step)."""
     if isinstance(request.param, tuple):
         harness.exact_host_set_parallel(*request.param)
     else:
@@ -299,13 +301,18 @@ def test_gpu_exact_overflow_keeps_dense_result(engine, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(POA_WS_RING_GLOBAL="1"), dict(POA_WS_GROUP="16"), dict(POA_WS_GROUP="8", POA_WS_WAVES="2"),
                                  dict(POA_WS_STATIC="1"), dict(POA_WS_LANES="1"), dict(POA_WS_LANES="63", POA_WS_WAVES="4"),
-                                 dict(POA_EXACT_LDS="0"), dict(POA_EXACT_IMPL="lane")],
+                                 dict(POA_EXACT_LDS="0"), dict(POA_EXACT_IMPL="lane"),
+                                 dict(POA_EXACT_IMPL="flat"), dict(POA_EXACT_IMPL="flat", POA_PS_LEAN="0"),
+                                 dict(POA_EXACT_IMPL="flat", POA_PS_LANES="3", POA_WS_RING_GLOBAL="1"),
+                                 dict(POA_EXACT_IMPL="flat", POA_EXACT_LDS="0", POA_WS_STATIC="1")],
                          ids=["ring_in_global_memory", "four_queries_per_wave", "eight_queries_per_wave", "static_schedule",
-                              "one_entry_per_step", "63_entries_per_step", "graph_in_global_memory", "one_search_per_lane_kernel"])
+                              "one_entry_per_step", "63_entries_per_step", "graph_in_global_memory", "one_search_per_lane_kernel",
+                              "flat_schedule_lean_step", "flat_schedule_generic_code", "flat_3_lanes_ring_global", "flat_records_in_global_memory"])
 def test_gpu_replay_variants_are_bit_identical(engine, oracle, env):
-    """Every schedule / placement variant of the replay kernel returns the reference's alignments: the descriptor ring in
+    """Every schedule / placement variant of the replay kernels returns the reference's alignments: the descriptor ring in
     global memory (wide priority ranges), several queries per wave, the static schedule, single-entry and 63-entry steps,
-    the graph read from global memory, and the round-1 one-search-per-lane kernel."""
+    the graph read from global memory, the round-1 one-search-per-lane kernel, and the parallel-step kernel of round 3
+    (poa_fsearch.hpp: eight queries per wave with the lean step, four with the generic code in log mode)."""
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
