@@ -57,15 +57,38 @@ def _load_json(*rel):
         return None
 
 
+FORWARD_KERNEL_SOURCES = ("poa_forward_px.hpp", "poa_forward_packed.hpp", "poa_kernels.hpp", "poa_graph.hpp", "poa_graph.cpp")
+
+
+def forward_kernel_source_hash():
+    """(sha256[:16], file list) of the sources the forward / traceback kernels are compiled from: ties the PMC counters
+    committed under profiles/ to the kernels of this tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in FORWARD_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "poasta_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16], list(FORWARD_KERNEL_SOURCES)
+
+
 def valu_ceiling():
-    """Wave-instructions per second one SIMD issues for the packed-u16 / permute / DPP instructions the forward kernels are
-    made of, at 8 resident waves (profiles/microbench/valu_issue_r02.json, measured in-kernel on an MI355X)."""
-    mb = _load_json("profiles", "microbench", "valu_issue_r02.json")
-    if not mb:
-        return None
-    rates = [r["waves_per_simd"]["8"]["simd_instr_per_s_in_kernel"] for r in mb["results"]
-             if r["op"] in ("v_pk_add_u16 clamp", "v_pk_min_u16", "v_perm_b32", "v_mov_b32_dpp row_shr:1")]
-    return sum(rates) / len(rates) if rates else None
+    """(wave-instructions per second one SIMD issues for the packed-u16 / permute / DPP instructions the forward kernels are
+    made of, at 8 resident waves; source file).  Round 3's micro-benchmark (profiles/microbench/valu_issue.hip) starts all
+    waves of a launch together: the rate from the waves' own timers and the one from the launch time agree, and their mean is
+    the ceiling; with only the round-2 file at hand its in-kernel rate is used."""
+    for name in ("valu_issue_r03.json", "valu_issue_r02.json"):
+        mb = _load_json("profiles", "microbench", name)
+        if not mb:
+            continue
+        rates = []
+        for r in mb["results"]:
+            if r["op"] in ("v_pk_add_u16 clamp", "v_pk_min_u16", "v_perm_b32", "v_mov_b32_dpp row_shr:1"):
+                w8 = r["waves_per_simd"]["8"]
+                rates.append(0.5 * (w8["simd_instr_per_s_in_kernel"] + w8["simd_instr_per_s_launch"]) if mb.get("all_waves_start_together")
+                             else w8["simd_instr_per_s_in_kernel"])
+        if rates:
+            return sum(rates) / len(rates), "profiles/microbench/" + name
+    return None, None
 
 
 def main():
@@ -274,11 +297,13 @@ def main():
         avg_launch_ms = st["ms_forward"] / launches
         cells_per_launch = cells_rank * st["n_runs"] / launches
         alg_achieved = ALG_BYTES_PER_CELL * cells_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        kc = _load_json("profiles", "kernel_counters.json") or _load_json("profiles", "hbm_traffic.json") or {}
-        same = kc.get("workload") == "config2" and kc.get("queries") == args.queries and "POA_PLANES" not in os.environ
+        kc = _load_json("profiles", "kernel_counters.json") or {}
+        src_hash = forward_kernel_source_hash()[0]
+        stale = kc.get("csrc_sha16") != src_hash
+        same = kc.get("workload") == "config2" and kc.get("queries") == args.queries and "POA_PLANES" not in os.environ and not stale
         traffic = kc.get("hbm_bytes_per_launch") if same else None
         valu_insts = kc.get("sq_insts_valu_per_launch") if same else None
-        ceil_simd = valu_ceiling()
+        ceil_simd, ceil_src = valu_ceiling()
         if os.environ.get("POA_PLANES") == "32":
             kernel_name = "poa_forward_kernel<4, unsigned int>"
         elif os.environ.get("POA_COMPACT") == "0" or os.environ.get("POA_PACKED") == "0":
@@ -288,15 +313,20 @@ def main():
         roof = {"kernel": kernel_name, "avg_launch_ms": round(avg_launch_ms, 3), "launches_timed": launches,
                 "cells_per_launch": int(cells_per_launch),
                 "alg_bytes_per_cell": ALG_BYTES_PER_CELL, "alg_achieved_GBps": round(alg_achieved, 1),
-                "alg_frac_of_hbm_peak": round(alg_achieved / HBM_PEAK_GBPS, 4),
+                "alg_over_hbm_peak_ratio": round(alg_achieved / HBM_PEAK_GBPS, 4),   # not a fraction: the engine stores ~2.4 B/cell of the 12 charged
                 "traffic": traffic,
-                "traffic_frac": None if not traffic else round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "hbm_frac_physical": None if not traffic else round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "counters": {"file": "profiles/kernel_counters.json", "csrc_sha16_of_counters": kc.get("csrc_sha16"), "csrc_sha16_of_this_tree": src_hash,
+                             "usable": bool(same),
+                             "why_not": None if same else ("the committed PMC counters were taken from other forward-kernel sources than this tree's "
+                                                           "(re-run profiles/run_rocprof.sh)" if stale else "other workload / plane layout than the counters'")},
                 "traceback_ms_per_step": round(st["ms_traceback"] / max(st["n_runs"], 1), 3)}
         if valu_insts and ceil_simd:
             ach = valu_insts / (avg_launch_ms * 1e-3) / 1e9
             peak = ceil_simd * N_SIMD / 1e9
             salu_insts = kc.get("sq_insts_salu_per_launch")
             roof.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
+                         "peak_source": ceil_src,
                          "insts_per_cell": {"valu": round(valu_insts * 64 / cells_per_launch, 3),
                                             "salu": None if not salu_insts else round(salu_insts * 64 / cells_per_launch, 3)},
                          "note": "Instruction issue binds this kernel: achieved = SQ_INSTS_VALU per launch (PMC, profiles/kernel_counters.json) / "
@@ -309,7 +339,8 @@ def main():
         else:
             roof.update({"bound": "hbm", "achieved": round(alg_achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(alg_achieved / HBM_PEAK_GBPS, 4),
-                         "note": "12 B/cell accounting of SURVEY.md 8(d) (no PMC instruction count for this configuration in profiles/)"})
+                         "note": "12 B/cell accounting of SURVEY.md 8(d): no PMC instruction count usable for this run (see counters.why_not), "
+                                 "so the instruction-issue fraction and the physical HBM fraction are not reported"})
         line = {
             "metric": "Gcells/sec (aligned bases/sec in config), gap-affine POA alignment, 1k-node POA x 10k x 1 kbp queries per GPU",
             "value": round(gcells, 3), "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,6 +370,14 @@ def main():
             n_cpu = len(qs) if args.cpu_sample < 0 else min(args.cpu_sample, len(qs))
             line["cpu_baseline"], A = cpu_baseline(graph, qs[:n_cpu], n_rows)
             line["bit_exact"] = bit_exact(batch, costs, stream, res, A, n_cpu, cells_rank, flagged_total)
+            # what `value` is and is not, at the top level: the dense step returns the reference's scores and a co-optimal
+            # alignment; the mode whose alignments ARE the reference's is bit_exact
+            be = line["bit_exact"]
+            line["alignments_identical_fraction"] = round(be["dense_mode_alignments_identical"] / max(n_cpu, 1), 4)
+            line["bit_exact_value"] = be["value"]
+            line["bit_exact_alignments_identical_fraction"] = round(be["alignments_identical"] / max(n_cpu, 1), 4)
+            line["bit_exact_vs_cpu_baseline"] = round(be["value"] / line["cpu_baseline"]["value"], 2) if line["cpu_baseline"]["value"] else None
+            line["bit_exact_unpadded"] = bit_exact_unpadded(poa, graph, costs, stream, local_rank, args.queries, n_rows)
         print(json.dumps(line), flush=True)
     batch.close()
     if dist is not None:
@@ -467,6 +506,44 @@ def bit_exact(batch, costs, stream, dense_res, A, n_checked, cells_rank, dense_f
     except Exception:
         pass
     return out
+
+
+def bit_exact_unpadded(poa, graph, costs, stream, device, n_queries, n_rows):
+    """The same reads WITHOUT the ~75 random bases that pad them to 1 kbp (BASELINE.json's configs fix the query length; the
+    walks through the graph are ~925 bases long): how much of the replayed fraction and of the replay's cost is the padding's —
+    the min-gap heuristic prices the padding as one long insertion and the reference's search then sweeps the whole band of
+    diagonals it could be opened on."""
+    import numpy as np
+    from poasta_amd import aligner
+    from poasta_amd.graph import pack_queries
+    try:
+        qs = poa.queries(n_queries, length=0, seed=2)
+        qseq, qoff = pack_queries(qs)
+        b = aligner.ResidentBatch(graph, qseq, qoff, device=device)
+        cells = int(n_rows * (np.diff(qoff).astype(np.int64) + 1).sum())
+        b.run(costs, stream)
+        d = b.fetch(want_pairs=False)
+        cfg = aligner.make_config("hybrid", queue_entries_per_cell=0.25)
+        b.run(costs, stream, cfg); b.stats()
+        t0 = time.perf_counter()
+        b.run(costs, stream, cfg)
+        st = b.stats()
+        dt = time.perf_counter() - t0
+        hy = b.fetch(want_pairs=False)
+        out = {"queries": n_queries, "mean_length": round(float(np.diff(qoff).mean()), 1), "flagged_fraction": round(float((d.flags != 0).mean()), 4),
+               "value": round(cells / dt / 1e9, 3), "unit": "Gcells/s", "seconds": round(dt, 4), "replayed": int(hy.stats["n_exact"]),
+               "ms_replay": round(st["ms_exact"], 3)}
+        try:
+            sc = b.search_counters()
+            sel = sc[:, 3] > 0
+            if sel.any():
+                out["replay_pops_mean"] = round(float(sc[sel, 0].mean()), 1)
+        except Exception:
+            pass
+        b.close()
+        return out
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
 
 
 if __name__ == "__main__":

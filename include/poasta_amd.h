@@ -75,7 +75,8 @@ typedef struct poa_costs2 {
     uint8_t gap_extend1;
     uint8_t gap_open2;
     uint8_t gap_extend2;
-    uint8_t reserved[3];
+    uint8_t wide_planes;      /* 1: u32 planes whatever the bound on the score allows (A/B) */
+    uint8_t reserved[2];
 } poa_costs2_t;
 
 /* Which reference configuration the exact replay emulates (only the replay depends on it: heuristic and pruning
@@ -95,6 +96,39 @@ typedef struct poa_bound {
                                  query whatever `mode` says; POA_FLAG_TRUNCATED then only says that the alignment does
                                  not begin at the start node */
 
+/* Overrides of the choices the engine makes per call (plane layout, forward / traceback / replay kernel and their shapes) — for
+ * A/B measurements and for the tests that run every parity case under every variant.  poa_config_t.tune[k] == 0: the engine
+ * decides; else the entry holds (value + 1).  The library reads no environment variable: the Python binding fills this block from
+ * POA_<NAME> variables (poasta_amd/_lib.py: tune_from_env), a host that wants a variant for one call sets it in that call's config. */
+enum {
+    POA_TUNE_PLANES = 0,      /* 32: u32 planes */
+    POA_TUNE_COMPACT,         /* 0: three planes instead of the compact layout */
+    POA_TUNE_PACKED,          /* 0: scalar-arithmetic forward kernel */
+    POA_TUNE_RELATIVE,        /* 0 / 1: relative encoding off / on */
+    POA_TUNE_PX,              /* 0: adjacent-pairs packed kernel instead of pairs-across-quads */
+    POA_TUNE_MF,              /* 0 / 1 / 2: at most that many flag pairs beside the score */
+    POA_TUNE_MW,              /* 0: no multi-wave pipeline */
+    POA_TUNE_PXMW,            /* 0 / 1: 1024-column multi-wave kernel off / on */
+    POA_TUNE_FWD_QUADS,
+    POA_TUNE_FUSE_TB,
+    POA_TUNE_TB_GROUP,        /* lanes per traceback walk: 8 / 16 / 32 / 64 */
+    POA_TUNE_TB_DEPTH,        /* speculative steps per round trip */
+    POA_TUNE_EXACT_IMPL,      /* replay kernel: 1 one search per lane, 2 wave per query (default), 3 flat parallel steps */
+    POA_TUNE_EXACT_LANES,
+    POA_TUNE_EXACT_LDS,       /* 0: graph tables read from global memory */
+    POA_TUNE_WS_LANES,
+    POA_TUNE_WS_GROUP,
+    POA_TUNE_WS_WAVES,
+    POA_TUNE_WS_RING_GLOBAL,
+    POA_TUNE_WS_STATIC,
+    POA_TUNE_WS_CHUNK_CAP,
+    POA_TUNE_WS_PROF,         /* per-phase cycle counts of the replay kernel, printed by poa_batch_stats */
+    POA_TUNE_PS_LANES,
+    POA_TUNE_PS_LEAN,         /* 0: flat kernel with the generic code in log mode */
+    POA_TUNE_TIMING,          /* poa_align_batch: host-side timing printed to stderr */
+    POA_TUNE_COUNT = 32
+};
+
 typedef struct poa_config {
     uint32_t mode;            /* POA_MODE_* */
     uint32_t heuristic;       /* POA_HEURISTIC_* (replay only) */
@@ -106,6 +140,7 @@ typedef struct poa_config {
     poa_bound_t qry_free_end;
     poa_bound_t graph_free_begin;
     poa_bound_t graph_free_end;
+    uint32_t tune[POA_TUNE_COUNT]; /* overrides of the engine's own choices, read once per call; see POA_TUNE_* */
 } poa_config_t;
 #define POA_CFG_FULL_PLANES 1u /* keep all three score planes in memory (needed by poa_batch_fetch_planes); the default
                                   u16 layout stores M, a 4-bit code per cell instead of I, and only the D rows read back */

@@ -26,7 +26,7 @@ EXPORTS = ["poa_version", "poa_last_error", "poa_device_count", "poa_graph_creat
 
 class PoaCosts2(C.Structure):
     _fields_ = [("mismatch", C.c_uint8), ("gap_open1", C.c_uint8), ("gap_extend1", C.c_uint8), ("gap_open2", C.c_uint8),
-                ("gap_extend2", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+                ("gap_extend2", C.c_uint8), ("wide_planes", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
 
 class PoaCosts(C.Structure):
@@ -40,7 +40,33 @@ class PoaBound(C.Structure):
 class PoaConfig(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("heuristic", C.c_uint32), ("pruning", C.c_uint32), ("queue_entries_per_cell", C.c_float),
                 ("flags", C.c_uint32), ("span", C.c_uint32), ("qry_free_begin", PoaBound), ("qry_free_end", PoaBound),
-                ("graph_free_begin", PoaBound), ("graph_free_end", PoaBound)]
+                ("graph_free_begin", PoaBound), ("graph_free_end", PoaBound), ("tune", C.c_uint32 * 32)]
+
+
+# poa_config_t.tune (include/poasta_amd.h: POA_TUNE_*): the library reads no environment variable; A/B scripts and the variant
+# sweep set POA_<NAME> and this binding copies them into the config of every call (tune_from_env).
+TUNE_KEYS = ("PLANES", "COMPACT", "PACKED", "RELATIVE", "PX", "MF", "MW", "PXMW", "FWD_QUADS", "FUSE_TB", "TB_GROUP", "TB_DEPTH",
+             "EXACT_IMPL", "EXACT_LANES", "EXACT_LDS", "WS_LANES", "WS_GROUP", "WS_WAVES", "WS_RING_GLOBAL", "WS_STATIC",
+             "WS_CHUNK_CAP", "WS_PROF", "PS_LANES", "PS_LEAN", "TIMING")
+EXACT_IMPLS = {"lane": 1, "wave": 2, "flat": 3}
+
+
+def tune_from_env(cfg=None, **overrides):
+    """Fill cfg.tune from POA_<NAME> environment variables and keyword overrides (exact_impl="flat", ws_lanes=1, ...).
+    Returns cfg (a dense-mode PoaConfig if none was given), or None if nothing is set and no cfg was given."""
+    vals = {}
+    for i, k in enumerate(TUNE_KEYS):
+        v = overrides.get(k.lower(), os.environ.get("POA_" + k))
+        if v is None or v == "":
+            continue
+        vals[i] = EXACT_IMPLS[v] if (k == "EXACT_IMPL" and v in EXACT_IMPLS) else int(v)
+    if cfg is None:
+        if not vals:
+            return None
+        cfg = PoaConfig()
+    for i, v in vals.items():
+        cfg.tune[i] = v + 1
+    return cfg
 
 
 BOUND_UNBOUNDED, BOUND_INCLUDED, BOUND_EXCLUDED = 0, 1, 2

@@ -12,6 +12,7 @@ a different co-optimal alignment (0 = provably the reference's alignment; see DE
 `align_batch` is the data-parallel shape of `lasagna align` (src/bin/lasagna.rs:184-276).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -83,7 +84,8 @@ class GapAffine2Piece:
         return (self.cost_gap_open1 - self.cost_gap_open2 + den - 1) // den
 
     def _c(self):
-        return _lib.PoaCosts2(self.cost_mismatch, self.cost_gap_open1, self.cost_gap_extend1, self.cost_gap_open2, self.cost_gap_extend2)
+        return _lib.PoaCosts2(self.cost_mismatch, self.cost_gap_open1, self.cost_gap_extend1, self.cost_gap_open2, self.cost_gap_extend2,
+                              1 if os.environ.get("POA_PLANES") == "32" else 0)
 
 
 class Affine2PieceDijkstra:
@@ -144,7 +146,7 @@ MODES = {"dense": _lib.MODE_DENSE, "exact": _lib.MODE_EXACT, "hybrid": _lib.MODE
 
 
 def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, queue_entries_per_cell=0.0, full_planes=False,
-                aln_type=AlignmentType.Global):
+                aln_type=AlignmentType.Global, **tune):
     """poa_config_t: `mode` "dense" | "exact" (replay the reference's A* for every query: bit-identical
     tie-breaks) | "hybrid" (replay only the queries the dense pass could not certify); `aln_type` Global or EndsFree(...)."""
     cfg = _lib.PoaConfig(MODES[mode] if isinstance(mode, str) else int(mode), int(heuristic), 1 if pruning else 0,
@@ -153,6 +155,7 @@ def make_config(mode="dense", heuristic=_lib.HEURISTIC_MINGAP, pruning=True, que
         cfg.span = _lib.SPAN_ENDS_FREE
         for name, (kind, value) in zip(("qry_free_begin", "qry_free_end", "graph_free_begin", "graph_free_end"), aln_type.bounds):
             setattr(cfg, name, _lib.PoaBound(kind, value))
+    _lib.tune_from_env(cfg, **tune)   # kernel / layout overrides: POA_<NAME> variables, keyword arguments (poa_config_t.tune)
     return cfg
 
 
@@ -268,14 +271,17 @@ class ResidentBatch:
     def run(self, costs, stream=None, config=None):
         c = costs._c()
         if config is None:
+            config = _lib.tune_from_env()   # (a dense-mode config carrying the overrides, if any are set)
+        if config is None:
             _lib.check(_lib.lib().poa_batch_run(self.handle, C.byref(c), C.c_void_p(stream or 0)))
         else:
             _lib.check(_lib.lib().poa_batch_run_ex(self.handle, C.byref(c), C.byref(config), C.c_void_p(stream or 0)))
 
-    def fetch(self, want_pairs=True, pinned=False):
+    def fetch(self, want_pairs=True, pinned=False, copy=False):
         """Synchronise and copy the results to the host.  pinned=True: the destination buffers are page-locked (allocated
         once per batch through torch, if importable), which lets the device->host copy run at PCIe speed instead of through
-        the driver's staging of pageable memory."""
+        the driver's staging of pageable memory.  NB the arrays of a pinned fetch ALIAS those per-batch buffers: the next
+        pinned fetch of this batch overwrites them — pass copy=True (or copy what you keep) to get arrays of your own."""
         n = self.n
         bufs = self._host_buffers(want_pairs, pinned)
         score, flags, pair_off, pairs = bufs
@@ -284,6 +290,8 @@ class ResidentBatch:
                                               _p(flags), C.byref(st)))
         if want_pairs:
             pairs = pairs[:int(pair_off[n])]
+        if copy and pinned:
+            score, pairs, pair_off, flags = score.copy(), pairs.copy(), pair_off.copy(), flags.copy()
         return BatchResult(score, pairs, pair_off, flags, st.as_dict())
 
     def _host_buffers(self, want_pairs, pinned):
@@ -407,4 +415,6 @@ class PoastaAligner:
                                                  _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), self.device))
         if want_pairs:
             pairs = pairs[:int(pair_off[n])]
+        if copy and pinned:
+            score, pairs, pair_off, flags = score.copy(), pairs.copy(), pair_off.copy(), flags.copy()
         return BatchResult(score, pairs, pair_off, flags, st.as_dict())

@@ -21,6 +21,13 @@
 #include "poa_exact_kernel.hpp"
 #include "poa_wsearch.hpp"
 #include "poa_fsearch.hpp"
+
+// poa_config_t.tune: what a call overrides (the library reads no environment variable)
+struct TuneView {
+    int val[POA_TUNE_COUNT]; bool set[POA_TUNE_COUNT];
+    explicit TuneView(const poa_config_t* cfg) { for (int k = 0; k < POA_TUNE_COUNT; ++k) { set[k] = cfg && cfg->tune[k] != 0; val[k] = set[k] ? (int)cfg->tune[k] - 1 : 0; } }
+    const int* ptr(int k) const { return set[k] ? &val[k] : nullptr; }
+};
 #include "poa_kernels.hpp"
 #include "poa_forward_packed.hpp"
 #include "poa_forward_px.hpp"
@@ -219,6 +226,7 @@ struct poa_batch {
     DevBuf<uint32_t> d_ex_logs;        // parallel-step search (poa_fsearch.hpp): the lanes' push logs, per resident wave
     DevBuf<FlatGraph::RowRec> d_ex_rec; // per-row records of its lean step (FlatGraph::row_rec)
     bool exact_ready = false;
+    bool prof_on = false;              // the last run asked for the replay kernel's cycle counts (POA_TUNE_WS_PROF)
     uint32_t last_mode = 0;
 
     // one event set per run since the last stats call: [begin, (fwd_end, tb_end) per chunk..., end]
@@ -293,8 +301,8 @@ static uint32_t mw_waves(uint32_t strips) {
     return (strips + groups - 1) / groups;
 }
 
-static bool pxmw_ok(uint32_t count, uint32_t max_pitch) {
-    if (const char* v = getenv("POA_PXMW")) return atoi(v) != 0;
+static bool pxmw_ok(const TuneView& T, uint32_t count, uint32_t max_pitch) {
+    if (const int* v = T.ptr(POA_TUNE_PXMW)) return (*v) != 0;
     return (uint64_t)count * ((max_pitch + 1023) / 1024) >= 1024;
 }
 
@@ -566,6 +574,7 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
         }
         HIP_TRY(b->d_ex_status.alloc(std::max<uint32_t>(b->n_queries, 1)));
         HIP_TRY(b->d_ex_counters.alloc(4 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
+        HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));   // (diagnostics; once, not per chunk while a kernel may write it)
         HIP_TRY(hipMemcpy(b->d_succ_off.p, fg.succ_row_off.data(), fg.succ_row_off.size() * 4, hipMemcpyHostToDevice));
         if (!fg.succ_rows.empty()) HIP_TRY(hipMemcpy(b->d_succ_rows.p, fg.succ_rows.data(), fg.succ_rows.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_dist_min.p, fg.dist_min.data(), n * 4, hipMemcpyHostToDevice));
@@ -591,6 +600,8 @@ int poa_batch_run(poa_batch_t* b, const poa_costs_t* costs, void* stream_v) { re
 
 int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_t* cfg, void* stream_v) {
     if (!b || !costs) return fail(POA_ERR_INVALID_ARG, "poa_batch_run: null argument");
+    const TuneView T(cfg);   // what this call overrides, read once
+    b->prof_on = T.ptr(POA_TUNE_WS_PROF) != nullptr;
     uint32_t mode = cfg ? cfg->mode : POA_MODE_DENSE;
     if (mode > POA_MODE_HYBRID) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown mode");
     if (cfg && cfg->span > POA_SPAN_ENDS_FREE) return fail(POA_ERR_INVALID_ARG, "poa_batch_run_ex: unknown alignment span");
@@ -621,14 +632,14 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     const uint64_t ub = (b->max_len ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * b->max_len : 0) +
                         (fg.min_path_nodes ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * fg.min_path_nodes : 0);
     bool narrow = ub <= 65534;
-    if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
+    if (const int* pv = T.ptr(POA_TUNE_PLANES)) { if ((*pv) == 32) narrow = false; }
     // compact layout (u16 only): 4-bit codes instead of the I plane, D rows only where they are read back.
     // POA_CFG_FULL_PLANES (or POA_COMPACT=0) keeps all three planes, e.g. for poa_batch_fetch_planes.
     const bool want_full = cfg && (cfg->flags & POA_CFG_FULL_PLANES);
     bool compact = narrow && !want_full;
-    if (const char* cv = getenv("POA_COMPACT")) { if (atoi(cv) == 0) compact = false; }
+    if (const int* cv = T.ptr(POA_TUNE_COMPACT)) { if ((*cv) == 0) compact = false; }
     bool packed = true;  // packed-u16 arithmetic kernel for the compact layout (POA_PACKED=0: scalar u32 arithmetic)
-    if (const char* pv2 = getenv("POA_PACKED")) packed = atoi(pv2) != 0;
+    if (const int* pv2 = T.ptr(POA_TUNE_PACKED)) packed = (*pv2) != 0;
     // Scores beyond u16 (a read against a much longer graph, Global): store every cell relative to the depth potential
     // e * (row_depth - column) (FlatGraph::row_depth).  All moves keep non-negative costs there, so the saturation argument
     // above holds for the relative values, and the largest one on an optimal path is the end cell's:
@@ -636,9 +647,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
     // Only the pairs-across-quads kernels (compact layout) implement it; POA_RELATIVE=0 keeps u32 planes, =1 forces it
     // wherever the bound allows (A-B against the absolute encodings).
     const uint64_t rel_ub = 2 * ((uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * b->max_len);
-    bool relative = !narrow && rel_ub <= 65534 && !want_full && packed && !getenv("POA_PLANES") && !getenv("POA_COMPACT");
-    if (const char* rv = getenv("POA_RELATIVE")) {
-        if (atoi(rv) == 0) relative = false;
+    bool relative = !narrow && rel_ub <= 65534 && !want_full && packed && !T.ptr(POA_TUNE_PLANES) && !T.ptr(POA_TUNE_COMPACT);
+    if (const int* rv = T.ptr(POA_TUNE_RELATIVE)) {
+        if ((*rv) == 0) relative = false;
         else relative = rel_ub <= 65534 && !want_full && packed;
     }
     if (relative) { narrow = true; compact = true; }
@@ -671,13 +682,13 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
         return POA_OK;
     }
     uint32_t spec_depth = 12;  // traceback speculation depth (lanes per round) of the full-plane layouts; the compact one: see the launch below
-    if (const char* sv = getenv("POA_TB_DEPTH")) { const int v = atoi(sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
+    if (const int* sv = T.ptr(POA_TUNE_TB_DEPTH)) { const int v = (*sv); if (v >= 1 && v <= 64) spec_depth = (uint32_t)v; }
     int tb_group = 16;   // POA_TB_GROUP override (lanes per walk); default: chosen per chunk at the launch below
-    if (const char* gv = getenv("POA_TB_GROUP")) { const int v = atoi(gv); if (v == 8 || v == 16 || v == 32 || v == 64) tb_group = v; }
+    if (const int* gv = T.ptr(POA_TUNE_TB_GROUP)) { const int v = (*gv); if (v == 8 || v == 16 || v == 32 || v == 64) tb_group = v; }
     bool fuse_tb = false;  // measured slower (16.0 vs 13.4 ms): tracing waves hold slots without HBM traffic. trace each query in the epilogue of its forward wave (POA_FUSE_TB=0: separate launch)
-    if (const char* fv = getenv("POA_FUSE_TB")) fuse_tb = atoi(fv) != 0;
+    if (const int* fv = T.ptr(POA_TUNE_FUSE_TB)) fuse_tb = (*fv) != 0;
     int quads_override = 0;
-    if (const char* ov = getenv("POA_FWD_QUADS")) quads_override = atoi(ov);  // tuning override
+    if (const int* ov = T.ptr(POA_TUNE_FWD_QUADS)) quads_override = (*ov);  // tuning override
     size_t ev = 1;
     for (const auto& ch : PL.chunks) {
         TbParams tp;
@@ -723,19 +734,19 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             if (compact && packed) {
                 // queries longer than one strip: one workgroup per query, its strips pipelined over the waves (MW)
                 bool mw = max_pitch > 512 * quads;
-                if (const char* mv = getenv("POA_MW")) mw = mw && (atoi(mv) != 0 || relative);
+                if (const int* mv = T.ptr(POA_TUNE_MW)) mw = mw && ((*mv) != 0 || relative);
                 bool px = max_pitch <= 1024 && quads == 2 && (!fuse_tb || relative);  // one strip of up to 1024 columns: the pairs-across-quads kernel
-                if (const char* xv = getenv("POA_PX")) px = (px && atoi(xv) != 0) || (px && relative);
+                if (const int* xv = T.ptr(POA_TUNE_PX)) px = (px && (*xv) != 0) || (px && relative);
                 if (px) {
                     // scores below 0x3FFF (same bound as for u16, one power lower): two flags ride in the stored M value
                     // (below 0x0FFF: all four; POA_MF = 0 / 1 / 2 caps the variant for A-B runs)
                     int mf = relative ? 0 : (ub <= 4094 ? 2 : (ub <= 16382 ? 1 : 0));
-                    if (const char* fv2 = getenv("POA_MF")) mf = std::min(mf, std::max(0, atoi(fv2)));
+                    if (const int* fv2 = T.ptr(POA_TUNE_MF)) mf = std::min(mf, std::max(0, (*fv2)));
                     tp.code_fmt = mf == 2 ? 3u : (mf == 1 ? 2u : 1u);
                     if (mf == 2) hipLaunchKernelGGL(poa_forward_px_kernel<2>, dim3(blocks), dim3(256), 0, stream, fp);
                     else if (mf == 1) hipLaunchKernelGGL(poa_forward_px_kernel<1>, dim3(blocks), dim3(256), 0, stream, fp);
                     else hipLaunchKernelGGL(poa_forward_px_kernel<0>, dim3(blocks), dim3(256), 0, stream, fp);
-                } else if (mw && (relative || pxmw_ok(ch.count, max_pitch))) {
+                } else if (mw && (relative || pxmw_ok(T, ch.count, max_pitch))) {
                     // pairs-across-quads mapping, 1024-column strips pipelined over the waves of a workgroup
                     tp.code_fmt = 1;
                     const uint32_t waves = mw_waves((max_pitch + 1023) / 1024);
@@ -763,7 +774,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             uint32_t quads = max_pitch <= 256 ? 1 : (max_pitch <= 512 ? 2 : 4);  // 256 columns per quad (4 x u32 per lane)
             if (quads_override == 1 || quads_override == 2 || quads_override == 4) quads = (uint32_t)quads_override;
             bool mw = max_pitch > 1024;  // longer than the widest strip: pipeline the strips over the waves of a workgroup
-            if (const char* mv = getenv("POA_MW")) mw = mw && atoi(mv) != 0;
+            if (const int* mv = T.ptr(POA_TUNE_MW)) mw = mw && (*mv) != 0;
             if (mw) {
                 // 512-column strips (up to 16 waves per query) or 1024-column ones (up to 10): a query whose strips do not all
                 // fit one workgroup runs as several groups one after the other, and few long queries are latency bound per
@@ -794,9 +805,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             // (ms per batch; 64 lanes x depth 32 / 32 x 32 / 16 x 16): 1 024 walks 0.44 / 0.57 / 0.74, 4 096 walks 0.68 / 0.77 /
             // 0.84, 10 000 walks 1.22 / 0.97 / 1.05, 20 000 walks 2.22 / 1.79 / 1.35.
             int tbg = ch.count <= 6144 ? 64 : (ch.count <= 12288 ? 32 : 16);
-            if (getenv("POA_TB_GROUP")) tbg = tb_group;
+            if (T.ptr(POA_TUNE_TB_GROUP)) tbg = tb_group;
             TbParams tpg = tp;
-            if (!getenv("POA_TB_DEPTH")) tpg.spec_depth = tbg == 16 ? 16u : (compact ? 32u : spec_depth);
+            if (!T.ptr(POA_TUNE_TB_DEPTH)) tpg.spec_depth = tbg == 16 ? 16u : (compact ? 32u : spec_depth);
             if (compact && tbg == 16) {
                 hipLaunchKernelGGL((poa_traceback_kernel<uint16_t, true, 16>), dim3((ch.count + 15) / 16), dim3(256), 0, stream, tpg);
             } else if (compact && tbg == 32) {
@@ -855,30 +866,27 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             int lds_cap = 64 * 1024;
             (void)hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, b->device);
             const uint32_t graph_lds = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
-            const char* impl = getenv("POA_EXACT_IMPL");
-            const bool wave_search = !(impl && !strcmp(impl, "lane")) && win <= b->ex_n_prio;
+            const int* impl = T.ptr(POA_TUNE_EXACT_IMPL);   // 1 lane, 2 wave, 3 flat
+            const bool wave_search = !(impl && *impl == 1) && win <= b->ex_n_prio;
             // "flat": the parallel-step kernel (poa_fsearch.hpp) — bit-identical like the others, not the fastest yet
-            const bool par_search = wave_search && impl && !strcmp(impl, "flat");
+            const bool par_search = wave_search && impl && *impl == 3;
             if (par_search) {
                 // the next entries in pop order expanded at once, one per lane, several queries per wave (poa_fsearch.hpp)
                 FSearchParams pp;
                 pp.E = ep;
                 pp.chunks = reinterpret_cast<ExU4*>(b->d_ex_pool.p);
                 pp.chunk_cap = b->ex_pool_cap / BQ_CHUNK;
-                if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < pp.chunk_cap) pp.chunk_cap = (uint32_t)v; }
+                if (const int* cv = T.ptr(POA_TUNE_WS_CHUNK_CAP)) { const int v = (*cv); if (v >= 1 && (uint32_t)v < pp.chunk_cap) pp.chunk_cap = (uint32_t)v; }
                 pp.win = win;
                 pp.counters = b->d_ex_counters.p;
                 pp.max_lanes = 63;   // (capped at the group's lanes below)
-                if (const char* lv = getenv("POA_PS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) pp.max_lanes = (uint32_t)v; }
+                if (const int* lv = T.ptr(POA_TUNE_PS_LANES)) { const int v = (*lv); if (v >= 1 && v <= 63) pp.max_lanes = (uint32_t)v; }
                 pp.prof = nullptr;
-                if (getenv("POA_WS_PROF")) {
-                    HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
-                    pp.prof = b->d_ex_prof.p;
-                }
+                if (T.ptr(POA_TUNE_WS_PROF)) pp.prof = b->d_ex_prof.p;
                 // Lanes per query: a step commits a dozen lanes on the benchmark's reads, and the kernel waits for memory more than it
                 // issues — so four searches share a wave (16 lanes each), all stepping through one instruction stream.
                 pp.lean = (!fg.row_rec.empty() && !ends_free) ? 1u : 0u;
-                if (const char* lv = getenv("POA_PS_LEAN")) pp.lean = (pp.lean && atoi(lv) != 0) ? 1u : 0u;
+                if (const int* lv = T.ptr(POA_TUNE_PS_LEAN)) pp.lean = (pp.lean && (*lv) != 0) ? 1u : 0u;
                 const uint32_t group = pp.lean ? 8u : 16u;   // (the group sizes poa_fsearch.hpp is built for)
                 const uint32_t qpw = 64 / group;
                 pp.group = group;
@@ -892,12 +900,12 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 // falls back to for a row in a thousand, stay in global memory); without records the generic code runs in log mode
                 const uint64_t rec_b = pp.lean ? ((sizeof(FlatGraph::RowRec) * (uint64_t)fg.n + 15) & ~15ull) : 0;
                 const uint64_t stage_b = pp.lean ? rec_b : graph_lds;
-                bool ring_lds = ring_b + ps_lds_bytes() <= lds_budget && !getenv("POA_WS_RING_GLOBAL");
+                bool ring_lds = ring_b + ps_lds_bytes() <= lds_budget && !T.ptr(POA_TUNE_WS_RING_GLOBAL);
                 uint64_t per_wave = (ring_lds ? ring_b : 0) + ps_lds_bytes();
                 bool stage = stage_b + per_wave <= lds_budget;
-                if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
+                if (const int* gv = T.ptr(POA_TUNE_EXACT_LDS)) stage = stage && (*gv) != 0;
                 uint32_t wpb = (uint32_t)std::min<uint64_t>(8, (lds_budget - (stage ? stage_b : 0)) / per_wave);
-                if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && (uint32_t)v <= wpb) wpb = (uint32_t)v; }
+                if (const int* wv = T.ptr(POA_TUNE_WS_WAVES)) { const int v = (*wv); if (v >= 1 && (uint32_t)v <= wpb) wpb = (uint32_t)v; }
                 if (wpb < 1) return fail(POA_ERR_UNSUPPORTED, "exact replay: the step's logs do not fit the LDS");
                 pp.graph_lds = (stage && !pp.lean) ? graph_lds : 0;
                 pp.rec_lds = (stage && pp.lean) ? (uint32_t)rec_b : 0;
@@ -913,7 +921,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)(64 * wpb), lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
                 const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
-                if (n_blocks > resident && !getenv("POA_WS_STATIC")) {
+                if (n_blocks > resident && !T.ptr(POA_TUNE_WS_STATIC)) {
                     // persistent waves, longest expected search first (see the wave search below)
                     std::vector<uint32_t> sc(ch.count), ord(ch.count);
                     HIP_TRY(hipMemcpyAsync(sc.data(), b->d_score.p + ch.first, (size_t)ch.count * 4, hipMemcpyDeviceToHost, stream));
@@ -936,35 +944,32 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 wp.E = ep;
                 wp.chunks = reinterpret_cast<ExU4*>(b->d_ex_pool.p);
                 wp.chunk_cap = b->ex_pool_cap / BQ_CHUNK;
-                if (const char* cv = getenv("POA_WS_CHUNK_CAP")) { const int v = atoi(cv); if (v >= 1 && (uint32_t)v < wp.chunk_cap) wp.chunk_cap = (uint32_t)v; }
+                if (const int* cv = T.ptr(POA_TUNE_WS_CHUNK_CAP)) { const int v = (*cv); if (v >= 1 && (uint32_t)v < wp.chunk_cap) wp.chunk_cap = (uint32_t)v; }
                 wp.win = win;
                 wp.counters = b->d_ex_counters.p;
                 wp.max_lanes = 16;   // entries tested per step: runs of stale / pruned entries are short (1.85 pops per step)
-                if (const char* lv = getenv("POA_WS_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 63) wp.max_lanes = (uint32_t)v; }
+                if (const int* lv = T.ptr(POA_TUNE_WS_LANES)) { const int v = (*lv); if (v >= 1 && v <= 63) wp.max_lanes = (uint32_t)v; }
                 wp.prof = nullptr;
-                if (getenv("POA_WS_PROF")) {  // per-phase cycle counts of the wave search (diagnostics)
-                    HIP_TRY(b->d_ex_prof.alloc(8 * (size_t)std::max<uint32_t>(b->n_queries, 1)));
-                    wp.prof = b->d_ex_prof.p;
-                }
+                if (T.ptr(POA_TUNE_WS_PROF)) wp.prof = b->d_ex_prof.p;  // per-phase cycle counts of the wave search (diagnostics)
                 // Lanes per query.  One query per wave (64) with persistent scheduling is the default.  Several queries per wave
                 // (POA_WS_GROUP = 32 / 16 / 8 lanes each, all through one instruction stream) issue fewer instructions in
                 // all but lose: the iteration takes the union of the groups' code paths and every wave waits for its slowest
                 // query (measured on config 2, 10 000 queries: 1.09 s at 64 persistent, 1.83 s at 64 static, 1.49 / 1.85 /
                 // 2.53 s at 32 / 16 / 8).  Waves per block: as many as share one staged copy of the graph, at most 16.
                 uint32_t group = 64;
-                if (const char* gv = getenv("POA_WS_GROUP")) { const int v = atoi(gv); if (v == 8 || v == 16 || v == 32 || v == 64) group = (uint32_t)v; }
+                if (const int* gv = T.ptr(POA_TUNE_WS_GROUP)) { const int v = (*gv); if (v == 8 || v == 16 || v == 32 || v == 64) group = (uint32_t)v; }
                 uint32_t wpb = 16;
-                if (const char* wv = getenv("POA_WS_WAVES")) { const int v = atoi(wv); if (v >= 1 && v <= 16) wpb = (uint32_t)v; }
+                if (const int* wv = T.ptr(POA_TUNE_WS_WAVES)) { const int v = (*wv); if (v >= 1 && v <= 16) wpb = (uint32_t)v; }
                 const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 80u * 1024u);
                 bool ring_lds = false, stage = false;
                 for (;;) {
                     const uint64_t rb = (uint64_t)wpb * (64 / group) * win * 12;
-                    ring_lds = rb <= lds_budget && !getenv("POA_WS_RING_GLOBAL");
+                    ring_lds = rb <= lds_budget && !T.ptr(POA_TUNE_WS_RING_GLOBAL);
                     stage = graph_lds + (ring_lds ? rb : 0) <= lds_budget;
-                    if (const char* gv = getenv("POA_EXACT_LDS")) stage = stage && atoi(gv) != 0;
+                    if (const int* gv = T.ptr(POA_TUNE_EXACT_LDS)) stage = stage && (*gv) != 0;
                     if (group == 64 || (ring_lds && stage)) break;
                     // several queries per wave need everything in LDS: fewer waves per block first, then fewer queries per wave
-                    if (wpb > 2 && !getenv("POA_WS_WAVES")) wpb /= 2; else { group *= 2; if (!getenv("POA_WS_WAVES")) wpb = 16; }
+                    if (wpb > 2 && !T.ptr(POA_TUNE_WS_WAVES)) wpb /= 2; else { group *= 2; if (!T.ptr(POA_TUNE_WS_WAVES)) wpb = 16; }
                 }
                 const uint64_t ring_bytes = ring_lds ? (uint64_t)wpb * (64 / group) * win * 12 : 0;
                 wp.graph_lds = stage ? graph_lds : 0;
@@ -979,7 +984,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 const uint32_t per_block = wpb * (64 / group);
                 uint32_t n_blocks = (ch.count + per_block - 1) / per_block;
                 wp.work_counter = nullptr; wp.order = nullptr;
-                if (group == 64 && !getenv("POA_WS_STATIC")) {
+                if (group == 64 && !T.ptr(POA_TUNE_WS_STATIC)) {
                     // persistent waves: as many blocks as are resident at once; queries handed out longest-expected-search
                     // first (by the dense pass's score: more edits, more buckets).  The sort needs the scores on the host:
                     // one small copy behind the dense pass of this chunk.
@@ -1008,16 +1013,16 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
             // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.
             uint32_t lanes = (ch.count + 4095) / 4096;
             if (lanes > 64) lanes = 64;
-            if (const char* lv = getenv("POA_EXACT_LANES")) { const int v = atoi(lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
+            if (const int* lv = T.ptr(POA_TUNE_EXACT_LANES)) { const int v = (*lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
             ep.lanes_per_wave = lanes;
             // graph arrays in LDS when they fit beside three other blocks of the same CU (160 KB per CU)
             uint32_t lds_bytes = exact_lds_bytes(fg.n, ep.n_succ, ep.n_nbm);
             bool lds_graph = lds_bytes <= 160u * 1024u / 3u;
-            if (const char* gv = getenv("POA_EXACT_LDS")) lds_graph = lds_graph && atoi(gv) != 0;
+            if (const int* gv = T.ptr(POA_TUNE_EXACT_LDS)) lds_graph = lds_graph && (*gv) != 0;
             if (lds_graph && lds_bytes > 48u * 1024u)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(poa_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             ep.lds_graph = lds_graph ? 1u : 0u;
-            if (lds_graph && !getenv("POA_EXACT_LANES")) {
+            if (lds_graph && !T.ptr(POA_TUNE_EXACT_LANES)) {
                 // all blocks resident at once (no tail round): LDS bounds the blocks per CU
                 int cus = 256;
                 (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
@@ -1123,7 +1128,7 @@ int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     if (b->n_queries) HIP_TRY(hipMemcpy(out, b->d_ex_counters.p, (size_t)b->n_queries * 16, hipMemcpyDeviceToHost));
-    if (getenv("POA_WS_PROF") && b->d_ex_prof.p && b->n_queries) {
+    if (b->prof_on && b->d_ex_prof.p && b->n_queries) {
         std::vector<unsigned long long> pr(8 * (size_t)b->n_queries);
         HIP_TRY(hipMemcpy(pr.data(), b->d_ex_prof.p, pr.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long sum[8] = {0};
@@ -1137,6 +1142,14 @@ int poa_batch_fetch_search_counters(poa_batch_t* b, uint32_t* out) {
 
 int poa_batch_device_results(poa_batch_t* b, void** score, void** flags, void** pair_off, void** pairs) {
     if (!b) return fail(POA_ERR_INVALID_ARG, "poa_batch_device_results: null batch");
+    // the results of the last run: wait for it and report a multi-wave pipeline that gave up (as poa_batch_fetch / _stats do), so
+    // that a caller gathering straight from HBM (poasta_amd/dist.py) never ships the output of a failed run
+    if (b->ran) {
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipStreamSynchronize(b->last_stream));
+        const int prc = check_pipeline_error(b);
+        if (prc != POA_OK) return prc;
+    }
     if (score) *score = b->d_score.p;
     if (flags) *flags = b->d_flags.p;
     if (pair_off) *pair_off = b->d_pair_off.p;
@@ -1198,6 +1211,7 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
                        const uint8_t* qseq, const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
                        uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, int device) {
     if (!g || !costs || !qoff) return fail(POA_ERR_INVALID_ARG, "poa_align_batch: null argument");
+    const TuneView T(cfg);
     if (stats) std::memset(stats, 0, sizeof(*stats));
     // PoastaAligner::align, empty-graph shortcut (src/aligner/mod.rs:124-142): score 4*len, no pairs
     if (g->g.n_real == 0) {
@@ -1223,13 +1237,13 @@ int poa_align_batch_ex(const poa_graph_t* g, const poa_costs_t* costs, const poa
         const uint64_t ub = (max_len ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * max_len : 0) +
                             (g->g.min_path_nodes ? (uint64_t)costs->gap_open + (uint64_t)costs->gap_extend * g->g.min_path_nodes : 0);
         const bool dense = !cfg || (cfg->mode == POA_MODE_DENSE && cfg->span == POA_SPAN_GLOBAL);
-        if (dense && ub <= 65534 && !getenv("POA_PLANES")) {
+        if (dense && ub <= 65534 && !T.ptr(POA_TUNE_PLANES)) {
             size_t free_b = 0, total_b = 0;
             if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && elems * 2 < free_b / 2)
                 ws_hint = elems * 2;
         }
     }
-    const bool timing = getenv("POA_TIMING") != nullptr;
+    const bool timing = T.ptr(POA_TUNE_TIMING);
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     poa_batch_t* b = nullptr;
@@ -1300,9 +1314,10 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     if (fg.n_real == 0) {  // empty graph: mod.rs:124-142
         for (uint32_t i = 0; i < n_queries; ++i) {
             if (score) score[i] = (uint32_t)(4 * (qoff[i + 1] - qoff[i]));
-            if (flags) flags[i] = 0;
+            if (flags) flags[i] = POA_FLAG_EMPTY_GRAPH;
             if (pair_off) pair_off[i + 1] = 0;
         }
+        if (stats) { stats->n_queries = n_queries; stats->n_flagged = n_queries; }
         return POA_OK;
     }
     const uint32_t pitch = (uint32_t)((max_len + 64) & ~63ull);
@@ -1313,7 +1328,7 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     const uint64_t ub = (max_len ? (uint64_t)costs->gap_open1 + (uint64_t)costs->gap_extend1 * max_len : 0) +
                         (fg.min_path_nodes ? (uint64_t)costs->gap_open1 + (uint64_t)costs->gap_extend1 * fg.min_path_nodes : 0);
     bool narrow = ub <= 65534;
-    if (const char* pv = getenv("POA_PLANES")) { if (atoi(pv) == 32) narrow = false; }
+    if (costs->wide_planes) narrow = false;
     const uint64_t elem = narrow ? 2 : 4;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1336,8 +1351,12 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     P.qseq = d_q.p; P.qoff = d_qoff.p; P.pitch = pitch; P.planes = d_planes.p;
     P.x = costs->mismatch; P.o1 = costs->gap_open1; P.e1 = costs->gap_extend1; P.e2 = costs->gap_extend2; P.oe = (uint32_t)costs->gap_open1 + costs->gap_extend1;
     P.score = d_score.p; P.flags = d_flags.p; P.n_pairs = d_np.p; P.scratch = d_scratch.p; P.scratch_stride = stride;
-    hipEvent_t e0, e1, e2;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+    struct Events {   // destroyed on every way out
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() { for (auto ev : e) if (ev) (void)hipEventDestroy(ev); }
+    } evs;
+    for (auto& ev : evs.e) HIP_TRY(hipEventCreate(&ev));
+    hipEvent_t &e0 = evs.e[0], &e1 = evs.e[1], &e2 = evs.e[2];
     float ms_f = 0.f, ms_t = 0.f;
     std::vector<uint32_t> h_np(n_queries), h_flags(n_queries);
     std::vector<poa_aln_pair_t> h_scratch((size_t)chunk * stride);
@@ -1392,7 +1411,6 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
                 }
         }
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     if (score) HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_flags.data(), d_flags.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
     if (flags) std::memcpy(flags, h_flags.data(), (size_t)n_queries * 4);

@@ -51,7 +51,7 @@ def device_result_tensors(batch, device):
 def gather_result_tensors(score, flags, pair_off, pairs, group=None, dst=0):
     """Every rank calls this with its shard's results as tensors (all on one device type: HBM for nccl, CPU for gloo).
     Returns on EVERY rank the records of the whole batch in rank order, (score, flags, n_pairs) int64 tensors, and on `dst`
-    also the concatenated pairs [sum n_pairs, 2] (None elsewhere).  Two collectives: all_gather (records), gather (pairs)."""
+    also the concatenated pairs [sum n_pairs, 2] (None elsewhere).  all_gather (records), then grouped send / recv (pairs)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -65,7 +65,7 @@ def gather_result_tensors(score, flags, pair_off, pairs, group=None, dst=0):
     dist.all_gather(metas, meta, group=group)
     counts = [int(m[0]) for m in metas]
     pcounts = [int(m[1]) for m in metas]
-    max_n, max_p = max(counts + [1]), max(pcounts + [1])
+    max_n = max(counts + [1])
     # 2) fixed-stride records to every rank
     rec = torch.zeros((max_n, 3), dtype=torch.int64, device=dev)
     if n_local:
@@ -75,13 +75,26 @@ def gather_result_tensors(score, flags, pair_off, pairs, group=None, dst=0):
     recs = [torch.zeros_like(rec) for _ in range(world)]
     dist.all_gather(recs, rec, group=group)
     all_rec = torch.cat([recs[r][:counts[r]] for r in range(world)])
-    # 3) alignment pairs to the consumer (padded to the largest shard: gather wants equal shapes)
-    pbuf = torch.zeros((max_p, 2), dtype=torch.int32, device=dev)
-    if pairs.shape[0]:
-        pbuf[:pairs.shape[0]] = pairs
-    bufs = [torch.zeros_like(pbuf) for _ in range(world)] if rank == dst else None
-    dist.gather(pbuf, bufs, dst=dst, group=group)
-    all_pairs = torch.cat([bufs[r][:pcounts[r]] for r in range(world)]) if rank == dst else None
+    # 3) alignment pairs to the consumer: one buffer of exactly the batch's pairs at `dst`, every other rank sends its
+    #    shard straight into its slice (grouped send / recv — RCCL point to point under "nccl", each peer over its own xGMI
+    #    link; the sizes are known from step 1).  No padding to the largest shard, no `world` staging buffers at the root.
+    all_pairs = None
+    ops = []
+    if rank == dst:
+        offs = [0]
+        for c in pcounts:
+            offs.append(offs[-1] + c)
+        all_pairs = torch.empty((offs[-1], 2), dtype=torch.int32, device=dev)
+        if pcounts[rank]:
+            all_pairs[offs[rank]:offs[rank + 1]] = pairs
+        for r in range(world):
+            if r != dst and pcounts[r]:
+                ops.append(dist.P2POp(dist.irecv, all_pairs[offs[r]:offs[r + 1]], r if group is None else dist.get_global_rank(group, r), group))
+    elif pcounts[rank]:
+        ops.append(dist.P2POp(dist.isend, pairs.contiguous(), dst if group is None else dist.get_global_rank(group, dst), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return all_rec[:, 0], all_rec[:, 1], all_rec[:, 2], all_pairs
 
 

@@ -100,6 +100,8 @@ int main(int argc, char** argv) {
         }
         if (pos.size() != 1) throw PoastaError("expected one FASTA of reads");
         const aligner::Mode m = mode == "dense" ? aligner::Mode::Dense : (mode == "exact" ? aligner::Mode::Exact : aligner::Mode::Hybrid);
+        const bool mode_dense = mode == "dense";
+        bool warned_dense = false;
         graphs::POAGraph graph;
         if (!msa_path.empty()) graph = io::load_graph_from_fasta_msa(read_fasta(msa_path));
         // GapAffine::new(mismatch, extend, open): the reference's argument order (gap_affine.rs:27)
@@ -116,6 +118,21 @@ int main(int argc, char** argv) {
                 const aligner::AstarResult r = al.align(graph, rec.second);                   // poasta.rs:214
                 std::fprintf(stderr, "Aligned '%s' (len=%zu) - Score: %u, Alignment length: %zu, flags 0x%x\n", rec.first.c_str(),
                              rec.second.size(), r.score, r.alignment.size(), r.flags);
+                // The graph update consumes the alignment verbatim (poa.rs:171-321): an alignment that is not the reference's would
+                // send every later read down another graph.  A replay that ran out of workspace kept the dense tie-breaks
+                // (EXACT_OVERFLOW); where the reference itself would have panicked (REF_PANIC, and the truncated walk that goes
+                // with it) there is nothing to reproduce — stop, as the reference does.
+                if (r.flags & (POA_FLAG_EXACT_OVERFLOW | POA_FLAG_REF_PANIC)) {
+                    std::fprintf(stderr, "poasta_align_amd: read '%s': %s — not adding it to the graph\n", rec.first.c_str(),
+                                 (r.flags & POA_FLAG_REF_PANIC) ? "the reference would panic on this input (u32 score wrap)"
+                                                                : "the replay ran out of workspace (raise --queue-entries-per-cell)");
+                    return 2;
+                }
+                if (mode_dense && r.flags && !warned_dense) {
+                    std::fprintf(stderr, "poasta_align_amd: --mode dense: read '%s' has co-optimal alignments (flags 0x%x); the tie-break taken is the"
+                                         " reference's rule on the full table, not necessarily the reference's own — use --mode hybrid for its graph\n", rec.first.c_str(), r.flags);
+                    warned_dense = true;
+                }
                 if (alog) {
                     alog << rec.first << '\t' << rec.second << '\t' << r.alignment.size() << '\n';
                     for (const auto& ap : r.alignment)

@@ -2,6 +2,11 @@
 // second, for the instruction kinds the forward kernels are made of, at 1 / 2 / 4 / 8 resident waves per SIMD.
 // Each wave runs ITER x 32 instructions over 8 independent registers (dependency distance 8 >= the pipeline depth), nothing
 // else; blocks of 256 threads put one wave on each SIMD of a CU, W blocks per CU give W waves per SIMD.
+// Round 3: every wave first waits at a counter in global memory until ALL waves of the launch have arrived, so that the W waves
+// of a SIMD run their whole loop side by side (in round 2 the waves started as they were dispatched: a wave's own lifetime was
+// shorter than the launch, and the two rates derived from them differed by 1.8x).  Reported per op and W: cycles (s_memtime) per
+// instruction and SIMD, the shader clock those cycles ran at (cycles / 100 MHz wall clock), and the two rates — per-wave timer
+// and launch time — which now agree.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip && ./valu_issue > valu_issue.json
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,8 +20,14 @@ constexpr int ITER = 4000;
 #define REP32(OP) REP8(OP) REP8(OP) REP8(OP) REP8(OP)
 
 template <int KIND>
-__global__ __launch_bounds__(256) void bench(uint32_t* out, unsigned long long* cyc, uint32_t k) {
+__global__ __launch_bounds__(256) void bench(uint32_t* out, unsigned long long* cyc, uint32_t k, uint32_t* arrived, uint32_t n_waves) {
     uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    // all waves of the launch resident and here before any starts its loop (bounded spin: a launch that does not fit would hang)
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(arrived, 1u);
+        for (uint32_t spin = 0; spin < (1u << 22) && __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_waves; ++spin) __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_wave_barrier();
     const unsigned long long t0 = clock64(), w0 = wall_clock64();
     for (int i = 0; i < ITER; ++i) {
         if (KIND == 0) {
@@ -51,17 +62,20 @@ __global__ __launch_bounds__(256) void bench(uint32_t* out, unsigned long long* 
 }
 
 template <int KIND>
-int run(const char* name, int cus, uint32_t* d_out, unsigned long long* d_cyc, bool first) {
+int run(const char* name, int cus, uint32_t* d_out, unsigned long long* d_cyc, uint32_t* d_arr, bool first) {
     const int ws[4] = {1, 2, 4, 8};
     printf("%s  {\"op\": \"%s\", \"waves_per_simd\": {", first ? "" : ",\n", name);
     for (int wi = 0; wi < 4; ++wi) {
         const int W = ws[wi], blocks = cus * W;
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 3u);  // warm
+        CHECK(hipMemset(d_arr, 0, 4));
+        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 3u, d_arr, (uint32_t)blocks * 4);  // warm
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemset(d_arr, 0, 4));
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 3u);
+        hipLaunchKernelGGL(bench<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 3u, d_arr, (uint32_t)blocks * 4);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -75,8 +89,10 @@ int run(const char* name, int cus, uint32_t* d_out, unsigned long long* d_cyc, b
         // per SIMD: W waves x instr_per_wave instructions in the wave's lifetime (in-kernel clock) resp. the launch (events)
         const double wall_s = w / 100e6;  // wall_clock64: 100 MHz
         printf("%s\"%d\": {\"launch_ms\": %.4f, \"wave_cycles_clock64\": %.0f, \"wave_us_wallclock\": %.2f, "
-               "\"simd_instr_per_s_in_kernel\": %.4g, \"simd_instr_per_s_launch\": %.4g, \"clock64_per_instr_per_wave\": %.3f}",
-               wi ? ", " : "", W, ms, c, wall_s * 1e6, W * instr_per_wave / wall_s, W * instr_per_wave / (ms * 1e-3), c / instr_per_wave);
+               "\"simd_instr_per_s_in_kernel\": %.4g, \"simd_instr_per_s_launch\": %.4g, \"clock64_per_instr_per_wave\": %.3f, "
+               "\"cycles_per_instr_per_simd\": %.3f, \"shader_clock_ghz\": %.3f}",
+               wi ? ", " : "", W, ms, c, wall_s * 1e6, W * instr_per_wave / wall_s, W * instr_per_wave / (ms * 1e-3), c / instr_per_wave,
+               c / (instr_per_wave * W), c / wall_s / 1e9);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     printf("}}");
@@ -88,16 +104,17 @@ int main() {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     int clk_khz = 0;
     (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
-    uint32_t* d_out; unsigned long long* d_cyc;
+    uint32_t* d_out; unsigned long long* d_cyc; uint32_t* d_arr;
+    CHECK(hipMalloc(&d_arr, 4));
     CHECK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4));
     CHECK(hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * 2 * 8));
-    printf("{\"device_cus\": %d, \"clock_rate_khz\": %d, \"instr_per_wave\": %d, \"results\": [\n", cus, clk_khz, ITER * 32);
-    if (run<0>("v_pk_add_u16", cus, d_out, d_cyc, true)) return 1;
-    if (run<4>("v_pk_add_u16 clamp", cus, d_out, d_cyc, false)) return 1;
-    if (run<1>("v_pk_min_u16", cus, d_out, d_cyc, false)) return 1;
-    if (run<2>("v_perm_b32", cus, d_out, d_cyc, false)) return 1;
-    if (run<3>("v_mov_b32_dpp row_shr:1", cus, d_out, d_cyc, false)) return 1;
-    if (run<5>("v_add_u32", cus, d_out, d_cyc, false)) return 1;
+    printf("{\"device_cus\": %d, \"clock_rate_khz\": %d, \"instr_per_wave\": %d, \"all_waves_start_together\": true, \"results\": [\n", cus, clk_khz, ITER * 32);
+    if (run<0>("v_pk_add_u16", cus, d_out, d_cyc, d_arr, true)) return 1;
+    if (run<4>("v_pk_add_u16 clamp", cus, d_out, d_cyc, d_arr, false)) return 1;
+    if (run<1>("v_pk_min_u16", cus, d_out, d_cyc, d_arr, false)) return 1;
+    if (run<2>("v_perm_b32", cus, d_out, d_cyc, d_arr, false)) return 1;
+    if (run<3>("v_mov_b32_dpp row_shr:1", cus, d_out, d_cyc, d_arr, false)) return 1;
+    if (run<5>("v_add_u32", cus, d_out, d_cyc, d_arr, false)) return 1;
     printf("\n]}\n");
     return 0;
 }

@@ -16,7 +16,9 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_
 done
 # summaries: kernel stats (trace) and counters per kernel (one launch each: --steps 1 --warmup 0)
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, sys
+sys.path.insert(0, "$ROOT")
+from bench import forward_kernel_source_hash
 out = collections.defaultdict(dict)
 for f in glob.glob("$OUT/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -31,6 +33,7 @@ if k and "WRITE_SIZE" in k and "FETCH_SIZE" in k:
           "hbm_bytes_per_launch": int(w + fch), "write_bytes": int(w), "fetch_bytes_corrected": int(fch),
           "sq_insts_valu_per_launch": k.get("SQ_INSTS_VALU"), "sq_insts_salu_per_launch": k.get("SQ_INSTS_SALU"),
           "sq_wave_cycles": k.get("SQ_WAVE_CYCLES"), "sq_wait_inst_any": k.get("SQ_WAIT_INST_ANY"), "sq_waves": k.get("SQ_WAVES"),
+          "csrc_sha16": forward_kernel_source_hash()[0], "hashed_files": forward_kernel_source_hash()[1],
           "source": "profiles/run_rocprof.sh $TAG: rocprofv3 --pmc in separate passes, one launch each (bench.py --steps 1 --warmup 0)",
           "note": "WRITE_SIZE / FETCH_SIZE in KiB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)"}
     json.dump(kc, open("$OUT/kernel_counters.json", "w"), indent=1)
