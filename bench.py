@@ -101,12 +101,17 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="queries timed on the CPU baseline at all cores (-1 = the whole batch, 0 = skip baseline and bit_exact)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--model", default="affine", choices=["affine", "2piece"],
+                    help="2piece: an extra, not the headline — the two-piece affine dense pass (poa_align_batch_2piece, SURVEY.md 8(f) row 3) "
+                         "on the configs[1] shape under the CLI's example costs -g 6,24 -e 2,1; one GPU; prints its own JSON line")
     ap.add_argument("--no-extras", action="store_true", help="skip like_for_like / value_incl_d2h / bit_exact (profiling runs)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU (or none for the spawn path): every rank uses cuda:0 and the gather runs "
                          "over gloo on CPU tensors (not a measurement)")
     args = ap.parse_args()
 
+    if args.model == "2piece":
+        return bench_two_piece(args)
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         # no launcher: become one.  Nothing has touched the GPU yet (torch is not even imported).
@@ -506,6 +511,44 @@ def bit_exact(batch, costs, stream, dense_res, A, n_checked, cells_rank, dense_f
     except Exception:
         pass
     return out
+
+
+def bench_two_piece(args):
+    """Extra: the two-piece affine model's dense pass (forward kernel poa2_forward_kernel + traceback poa2_traceback_kernel) over
+    configs[1]'s graph and reads, through the one-shot C entry point (host buffers in, host buffers out; the kernel times are HIP
+    events inside it).  roofline: HBM — the five planes M, D1, D2, I1, I2 a traceback of this model reads (20 B/cell as u32, the
+    algorithmic unit in the sense of SURVEY.md 8(d); the engine stores them as u16 under the score bound: 10 B/cell physical)."""
+    import numpy as np
+    from poasta_amd import aligner, workloads
+    n = min(args.queries, 8000)
+    g, (qseq, qoff) = workloads.config2(n_queries=n, length=args.length)
+    al = aligner.PoastaAligner(aligner.Affine2PieceDijkstra(aligner.GapAffine2Piece(4, 2, 6, 1, 24)))   # poasta align -g 6,24 -e 2,1
+    al.align_batch(g, qseq=qseq[:int(qoff[8])], qoff=qoff[:9])
+    best = None
+    for _ in range(max(1, args.warmup) + max(1, min(args.steps, 3))):
+        t0 = time.perf_counter()
+        res = al.align_batch(g, qseq=qseq, qoff=qoff)
+        dt = time.perf_counter() - t0
+        if best is None or res.stats["ms_forward"] < best[1]["ms_forward"]:
+            best = (dt, res.stats)
+    dt, st = best
+    cells, ms_f, ms_t = st["cells"], st["ms_forward"], st["ms_traceback"]
+    launches = max(st["n_forward_launches"], 1)
+    alg = 20.0 * cells / (ms_f * 1e-3) / 1e9
+    phys = st["plane_bytes"] / (ms_f * 1e-3) / 1e9
+    line = {"metric": "Gcells/sec, two-piece gap-affine POA dense pass (extra), 1k-node POA x %d x 1 kbp queries" % n,
+            "value": round(cells / ((ms_f + ms_t) * 1e-3) / 1e9, 3), "unit": "Gcells/s (forward + traceback kernels)", "n_gpus": 1,
+            "higher_is_better": True, "dtype": "u16" if st["plane_bytes"] == cells * 10 else "u32", "data": "synthetic", "vs_baseline": None,
+            "config": {"workload": "BASELINE.json configs[1] graph and reads (%d queries), GapAffine2Piece(mismatch 4, extend1 2, open1 6, extend2 1, open2 24), Global" % n,
+                       "chunks": st["n_chunks"], "one_shot_call_s": round(dt, 3)},
+            "forward_gcells_per_s": round(cells / (ms_f * 1e-3) / 1e9, 2), "ms_forward": round(ms_f, 3), "ms_traceback": round(ms_t, 3),
+            "roofline": {"kernel": "poa2_forward_kernel", "bound": "hbm", "achieved": round(alg, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(alg / HBM_PEAK_GBPS, 4), "alg_bytes_per_cell": 20.0, "avg_launch_ms": round(ms_f / launches, 3), "launches_timed": launches,
+                         "stored_bytes_per_cell": round(st["plane_bytes"] / cells, 2), "stored_GBps": round(phys, 1), "hbm_frac_physical_stores_only": round(phys / HBM_PEAK_GBPS, 4),
+                         "traffic": None,
+                         "note": "achieved = 20 B/cell (five u32 planes: the reference's visited cell of this model) x cells / forward time, HIP events inside the "
+                                 "call; the engine writes the planes as u16 when the score bound allows (stored_*); PMC traffic: profiles/r03_two_piece/"}}
+    print(json.dumps(line), flush=True)
 
 
 def bit_exact_unpadded(poa, graph, costs, stream, device, n_queries, n_rows):

@@ -197,6 +197,14 @@ int poa_graph_create(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
                      const uint32_t* succ_off, const uint32_t* succ,
                      const uint32_t* pred_off, const uint32_t* pred, poa_graph_t** out);
 void poa_graph_destroy(poa_graph_t* g);
+/* Refresh a graph handle after the host graph changed (POAGraph::add_alignment_with_weights + post_process,
+ * src/graphs/poa.rs:171-363: nodes appended, edges added, start / end edges re-wired): same arguments as poa_graph_create, the
+ * handle stays the same object.  The row tables are re-flattened in place (O(N + E) on the host — microseconds at the sizes of a
+ * sequential POA build, under 1 % of a read's alignment call: scripts/sequential_poa_latency.sh); batches created from the
+ * handle before the call keep the tables they copied and must not be run again. */
+int poa_graph_update(poa_graph_t* g, uint32_t n_nodes_with_start_end, uint32_t start, uint32_t end, const uint8_t* symbol,
+                     const uint32_t* succ_off, const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred);
+
 uint32_t poa_graph_rows(const poa_graph_t* g);           /* == n */
 /* row (topological rank used for the score planes) of every node; rank[n] */
 int poa_graph_node_rows(const poa_graph_t* g, uint32_t* rank);

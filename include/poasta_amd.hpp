@@ -77,7 +77,7 @@ public:
 
     NodeIndex add_node(uint8_t sym) {
         symbol_.push_back(sym); succ_.emplace_back(); pred_.emplace_back(); aligned_nodes_.emplace_back();
-        flat_.reset();
+        flat_dirty_ = true;
         return (NodeIndex)symbol_.size() - 1;
     }
     // POAGraph::add_edge (poa.rs:118-134): an existing edge keeps its position, gets the sequence id and the weight added
@@ -88,7 +88,7 @@ public:
         if (std::find(succ_[s].begin(), succ_[s].end(), t) != succ_[s].end()) return;
         succ_[s].insert(succ_[s].begin(), t);
         pred_[t].insert(pred_[t].begin(), s);
-        flat_.reset();
+        flat_dirty_ = true;
     }
     // poa.rs:136-169; returns (first, last)
     std::optional<std::pair<NodeIndex, NodeIndex>> add_nodes_for_sequence(const std::string& seq, size_t start, size_t end,
@@ -169,16 +169,17 @@ public:
             if (v != s && v != e && pred_[v].empty()) { succ_[s].insert(succ_[s].begin(), v); pred_[v].insert(pred_[v].begin(), s); }
         for (NodeIndex v = 0; v < n; ++v)
             if (v != s && v != e && succ_[v].empty()) { succ_[v].insert(succ_[v].begin(), e); pred_[e].insert(pred_[e].begin(), v); }
-        flat_.reset();
+        flat_dirty_ = true;
     }
 
-    // The flattened AlignableRefGraph handed to the device library (built lazily, by iterating the trait).
+    // The flattened AlignableRefGraph handed to the device library (built lazily, by iterating the trait; after a graph update the
+    // same handle is refreshed in place: poa_graph_update).
     struct Flat {
         poa_graph_t* handle = nullptr;
         ~Flat() { if (handle) poa_graph_destroy(handle); }
     };
     const poa_graph_t* device_graph() const {
-        if (!flat_) {
+        if (!flat_ || flat_dirty_) {
             const uint32_t n = (uint32_t)symbol_.size();
             std::vector<uint32_t> so(n + 1, 0), po(n + 1, 0), s, p;
             for (uint32_t v = 0; v < n; ++v) {
@@ -186,10 +187,16 @@ public:
                 for (NodeIndex t : pred_[v]) p.push_back(t);
                 so[v + 1] = (uint32_t)s.size(); po[v + 1] = (uint32_t)p.size();
             }
-            auto f = std::make_shared<Flat>();
-            const int rc = poa_graph_create(n, start_node(), end_node(), symbol_.data(), so.data(), s.data(), po.data(), p.data(), &f->handle);
-            if (rc != POA_OK) throw PoastaError(std::string("poa_graph_create: ") + poa_last_error());
-            flat_ = f;
+            if (flat_) {
+                const int rc = poa_graph_update(flat_->handle, n, start_node(), end_node(), symbol_.data(), so.data(), s.data(), po.data(), p.data());
+                if (rc != POA_OK) throw PoastaError(std::string("poa_graph_update: ") + poa_last_error());
+            } else {
+                auto f = std::make_shared<Flat>();
+                const int rc = poa_graph_create(n, start_node(), end_node(), symbol_.data(), so.data(), s.data(), po.data(), p.data(), &f->handle);
+                if (rc != POA_OK) throw PoastaError(std::string("poa_graph_create: ") + poa_last_error());
+                flat_ = f;
+            }
+            flat_dirty_ = false;
         }
         return flat_->handle;
     }
@@ -198,7 +205,8 @@ private:
     std::vector<uint8_t> symbol_;
     std::vector<std::vector<NodeIndex>> succ_, pred_, aligned_nodes_;
     std::map<uint64_t, POAEdgeData> edges_;   // start / end edges carry no data (poa.rs:73-78)
-    mutable std::shared_ptr<Flat> flat_;      // the device copy: rebuilt from the trait view after a graph update (O(N + E), host)
+    mutable std::shared_ptr<Flat> flat_;      // the library's handle: refreshed from the trait view after a graph update (O(N + E), host)
+    mutable bool flat_dirty_ = false;
 public:
     // used by io::load_graph_from_fasta_msa (it wires aligned_nodes itself, graph.rs:71-85)
     void link_aligned_nodes(NodeIndex a, NodeIndex b) { aligned_nodes_[a].push_back(b); aligned_nodes_[b].push_back(a); }

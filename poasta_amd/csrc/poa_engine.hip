@@ -337,6 +337,23 @@ int poa_graph_create(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sy
 
 void poa_graph_destroy(poa_graph_t* g) { delete g; }
 uint32_t poa_graph_rows(const poa_graph_t* g) { return g ? g->g.n : 0; }
+int poa_graph_update(poa_graph_t* g, uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
+                     const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred) {
+    if (!g) return fail(POA_ERR_INVALID_ARG, "poa_graph_update: null graph");
+    std::string err;
+    int rc;
+    FlatGraph ng;
+    try {
+        rc = build_flat_graph(n, start, end, symbol, succ_off, succ, pred_off, pred, ng, err);
+    } catch (const std::bad_alloc&) {
+        return fail(POA_ERR_OUT_OF_MEMORY, "poa_graph_update: host allocation failed");
+    }
+    if (rc != POA_OK) return fail(rc, err);   // (the handle keeps the graph it had)
+    std::lock_guard<std::mutex> lk(g->bubble_mu);
+    g->g = std::move(ng);
+    return POA_OK;
+}
+
 int poa_graph_node_rows(const poa_graph_t* g, uint32_t* rank) {
     if (!g || !rank) return fail(POA_ERR_INVALID_ARG, "poa_graph_node_rows: null argument");
     std::memcpy(rank, g->g.node_row.data(), g->g.n * sizeof(uint32_t));

@@ -9,6 +9,7 @@
 //   poasta_align_amd align [-n MISMATCH] [-g OPEN] [-e EXTEND] [-I graph.msa.fa] [-o OUT] [--mode dense|exact|hybrid]
 //                          [--device N] [--alignments FILE] READS.fa
 //   poasta_align_amd replay ALIGNMENTS.txt          (no GPU: graph update + export from recorded alignments)
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -78,12 +79,12 @@ int main(int argc, char** argv) {
     try {
         if (argc >= 3 && std::strcmp(argv[1], "replay") == 0) return replay(argv[2]);
         if (argc < 3 || std::strcmp(argv[1], "align") != 0) {
-            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6] [-e 2] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--device 0] [--alignments file] reads.fa\n"
+            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6] [-e 2] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--device 0] [--alignments file] [--timing file.tsv] reads.fa\n"
                                  "       poasta_align_amd replay alignments.txt\n");
             return 2;
         }
         int mismatch = 4, open = 6, extend = 2, device = 0;
-        std::string out_path, msa_path, aln_path, mode = "hybrid";
+        std::string out_path, msa_path, aln_path, timing_path, mode = "hybrid";
         std::vector<std::string> pos;
         for (int i = 2; i < argc; ++i) {
             const std::string a = argv[i];
@@ -96,6 +97,7 @@ int main(int argc, char** argv) {
             else if (a == "--mode") mode = need("--mode");
             else if (a == "--device") device = std::stoi(need("--device"));
             else if (a == "--alignments") aln_path = need("--alignments");
+            else if (a == "--timing") timing_path = need("--timing");
             else pos.push_back(a);
         }
         if (pos.size() != 1) throw PoastaError("expected one FASTA of reads");
@@ -107,15 +109,25 @@ int main(int argc, char** argv) {
         // GapAffine::new(mismatch, extend, open): the reference's argument order (gap_affine.rs:27)
         aligner::PoastaAligner<aligner::AffineMinGapCost> al(aligner::AffineMinGapCost(aligner::GapAffine((uint8_t)mismatch, (uint8_t)extend, (uint8_t)open)),
                                                              aligner::AlignmentType::Global, device, m);
-        std::ofstream alog;
+        std::ofstream alog, tlog;
+        if (!timing_path.empty()) { tlog.open(timing_path); tlog << "read\tlen\tgraph_nodes\tus_graph_refresh\tus_align_call\tus_h2d\tus_dense_kernels\tus_replay\tus_d2h\tus_graph_update\n"; }
         if (!aln_path.empty()) alog.open(aln_path);
         for (const auto& rec : read_fasta(pos[0])) {
             const std::vector<size_t> weights(rec.second.size(), 1);
+            using clk = std::chrono::steady_clock;
+            auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
             if (graph.is_empty()) {
                 graph.add_alignment_with_weights(rec.first, rec.second, nullptr, weights);   // poasta.rs:209-211
                 if (alog) alog << rec.first << '\t' << rec.second << "\t-\n";
             } else {
-                const aligner::AstarResult r = al.align(graph, rec.second);                   // poasta.rs:214
+                // per-read latency of BASELINE.json configs[0]'s shape (--timing): the handle's refresh after the last graph update,
+                // the alignment call (upload, dense pass, replay of the flagged read, download), the graph update
+                const auto t0 = clk::now();
+                (void)graph.device_graph();                                                   // poa_graph_update: re-flatten in place
+                const auto t1 = clk::now();
+                poa_stats_t st{};
+                const aligner::AstarResult r = al.align_batch(graph, {rec.second}, true, &st).at(0);   // poasta.rs:214
+                const auto t2 = clk::now();
                 std::fprintf(stderr, "Aligned '%s' (len=%zu) - Score: %u, Alignment length: %zu, flags 0x%x\n", rec.first.c_str(),
                              rec.second.size(), r.score, r.alignment.size(), r.flags);
                 // The graph update consumes the alignment verbatim (poa.rs:171-321): an alignment that is not the reference's would
@@ -139,6 +151,9 @@ int main(int argc, char** argv) {
                         alog << (ap.rpos ? (long long)*ap.rpos : -1LL) << ' ' << (ap.qpos ? (long long)*ap.qpos : -1LL) << '\n';
                 }
                 graph.add_alignment_with_weights(rec.first, rec.second, &r.alignment, weights);   // poasta.rs:226
+                const auto t3 = clk::now();
+                if (tlog) tlog << rec.first << '\t' << rec.second.size() << '\t' << graph.node_count_with_start_and_end() << '\t' << us(t0, t1) << '\t' << us(t1, t2) << '\t'
+                               << st.ms_h2d * 1e3 << '\t' << (st.ms_forward + st.ms_traceback) * 1e3 << '\t' << st.ms_exact * 1e3 << '\t' << st.ms_d2h * 1e3 << '\t' << us(t2, t3) << '\n';
             }
         }
         const std::string fasta = io::poa_graph_to_fasta(graph);

@@ -91,18 +91,20 @@ def test_config5_full_size(engine, oracle):
 
 def test_config4_members(engine, oracle):
     """configs[3] graph (50 kbp x 32 haplotypes as an MSA, ~56 k rows), 10 kbp reads, Global: scores beyond u16 in 2-byte
-    cells (relative encoding) through the multi-wave pipeline, 40 k-row deletion runs in the traceback.  96 of the 5 000
-    queries (the full 5 000 with 8 oracle members: scripts/config_throughput.py --config 4, profiles/r02_relative/)."""
-    g, (qseq, qoff) = W.config4(n_queries=96)
+    cells (relative encoding) through the multi-wave pipeline, 40 k-row deletion runs in the traceback.  512 of the 5 000
+    queries in several plane chunks, 8 oracle members (the full 5 000: scripts/config_throughput.py --config 4,
+    profiles/r02_relative/)."""
+    g, (qseq, qoff) = W.config4(n_queries=512)
     rb = engine.ResidentBatch(g, qseq, qoff)
     rb.run(_costs(engine))
     res = rb.fetch()
     assert int(res.score.min()) > 65534 and int((res.score == NONE).sum()) == 0
     assert rb.layout() == {"u16", "compact", "relative"}
-    idx = [57]
-    qs = _check_members_against_oracle(engine, oracle, g, qseq, qoff, res, idx, threads=2)
+    assert res.stats["n_chunks"] > 1
+    idx = [3, 57, 121, 200, 266, 349, 430, 511]
+    qs = _check_members_against_oracle(engine, oracle, g, qseq, qoff, res, idx, threads=8)
     _check_batch_independence(engine, g, qs, res, idx)
-    _check_shape(res, qoff, range(0, 96, 3))
+    _check_shape(res, qoff, range(0, 512, 7))
     rb.close()
 
 
