@@ -74,8 +74,11 @@ def forward_kernel_source_hash():
 def valu_ceiling():
     """(wave-instructions per second one SIMD issues for the packed-u16 / permute / DPP instructions the forward kernels are
     made of, at 8 resident waves; source file).  Round 3's micro-benchmark (profiles/microbench/valu_issue.hip) starts all
-    waves of a launch together: the rate from the waves' own timers and the one from the launch time agree, and their mean is
-    the ceiling; with only the round-2 file at hand its in-kernel rate is used."""
+    waves of a launch together and takes the rate over the span first-wave-in .. last-wave-out of the loops on the device-wide
+    counter; it equals the rate from the launch time (0.567e9 per SIMD = one packed-u16 instruction per 4.2 cycles).  The
+    waves' OWN timers give 1.0e9 — round 2's ceiling — because a SIMD issues from its oldest ready wave first: the waves
+    finish one after the other, a wave's own elapsed time averages 9/16 of the span.  Only the round-2 file at hand: its
+    launch-derived rate."""
     for name in ("valu_issue_r03.json", "valu_issue_r02.json"):
         mb = _load_json("profiles", "microbench", name)
         if not mb:
@@ -84,8 +87,7 @@ def valu_ceiling():
         for r in mb["results"]:
             if r["op"] in ("v_pk_add_u16 clamp", "v_pk_min_u16", "v_perm_b32", "v_mov_b32_dpp row_shr:1"):
                 w8 = r["waves_per_simd"]["8"]
-                rates.append(0.5 * (w8["simd_instr_per_s_in_kernel"] + w8["simd_instr_per_s_launch"]) if mb.get("all_waves_start_together")
-                             else w8["simd_instr_per_s_in_kernel"])
+                rates.append(w8["simd_instr_per_s_span"] if "simd_instr_per_s_span" in w8 else w8["simd_instr_per_s_launch"])
         if rates:
             return sum(rates) / len(rates), "profiles/microbench/" + name
     return None, None

@@ -415,6 +415,4 @@ class PoastaAligner:
                                                  _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), self.device))
         if want_pairs:
             pairs = pairs[:int(pair_off[n])]
-        if copy and pinned:
-            score, pairs, pair_off, flags = score.copy(), pairs.copy(), pair_off.copy(), flags.copy()
         return BatchResult(score, pairs, pair_off, flags, st.as_dict())
