@@ -238,6 +238,21 @@ int poa_align_batch_2piece(const poa_graph_t* g, const poa_costs2_t* costs, uint
                            const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
                            poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
                            uint32_t* flags, poa_stats_t* stats, int device);
+/* Two-piece model with a mode (cfg NULL or mode DENSE == poa_align_batch_2piece).  Mode EXACT (HYBRID is taken as EXACT: under
+ * this model the dense certificate does not cover the cases where the reference's search is not optimal) replays the
+ * reference's own search per query — replaces `PoastaAligner::new(Affine2PieceMinGapCost(costs) | Affine2PieceDijkstra(costs),
+ * aln_type).align(graph, seq)` (src/aligner/config.rs:160-272, astar.rs:124-226 over scoring/gap_affine_2piece.rs: five
+ * states, stacks popped M, D1, D2, I1, I2 (:1069-1097), gap_cost / heuristic (:99-127, heuristic.rs:70-102), pruning with the
+ * second-piece branches of bubbles/reached.rs:84-124,:165-186, ends-free begin / end rules :179-290) — what
+ * `poasta align -g 6,24 -e 2,1` runs (src/bin/poasta.rs:319-445).  cfg->heuristic / pruning / span / bounds as in
+ * poa_align_batch_ex.  score[n] is the score the reference's search returns (which may exceed the dense optimum), pairs
+ * its backtrace (gap_affine_2piece.rs:639-794, :944-1043); flags: POA_FLAG_REF_PANIC, POA_FLAG_TRUNCATED,
+ * POA_FLAG_EXACT_OVERFLOW (queue pool: raise cfg->queue_entries_per_cell).  search_counters (may be NULL): 4 words per query —
+ * num_queued, num_visited, num_pruned (AstarResult, astar.rs:228) and the queue entries that were live at once. */
+int poa_align_batch_2piece_ex(const poa_graph_t* g, const poa_costs2_t* costs, const poa_config_t* cfg, uint32_t n_queries,
+                              const uint8_t* qseq, const uint64_t* qoff, uint32_t* score,
+                              poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity,
+                              uint32_t* flags, poa_stats_t* stats, uint32_t* search_counters, int device);
 /* debugging / parity: the five score planes M, I1, D1, I2, D2 of ONE query, rows x (len + 1) each, row = topological rank
  * (poa_graph_node_rows) */
 int poa_planes_2piece(const poa_graph_t* g, const poa_costs2_t* costs, const uint8_t* seq, uint32_t len,

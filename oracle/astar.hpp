@@ -322,13 +322,15 @@ public:
         for (auto it = reached.lower_bound(tmin); it != reached.end() && *it <= tmax; ++it) {
             const uint32_t* next = &*it;
             uint32_t offset1 = prev ? std::max(tmin, *prev + 1u) : tmin;
-            if (st == ST_D) {
+            // reached.rs:84-101 (a state inside a gap does not pay the open cost again; the second piece: gap_open2)
+            if (st == ST_D || st == ST_D2) {
                 Score c = visited.get_score({bubble.bubble_exit, *next}, ST_M);
-                if (score_add(c, costs.gap_open) > current) return true;
+                if (score_add(c, st == ST_D ? costs.gap_open : costs.gap_open2) > current) return true;
             }
-            if (prev && st == ST_I) {
+            // reached.rs:104-124
+            if (prev && (st == ST_I || st == ST_I2)) {
                 Score c = visited.get_score({bubble.bubble_exit, *prev}, ST_M);
-                if (score_add(c, costs.gap_open) > current) return true;
+                if (score_add(c, st == ST_I ? costs.gap_open : costs.gap_open2) > current) return true;
             }
             if (can_improve_at_offset(bubble.bubble_exit, offset1, current, prev, next, mde)) return true;
             uint32_t offset2 = std::min(tmax, std::max(tmin, *next - 1u));  // wrapping u32 sub
@@ -347,9 +349,9 @@ public:
         if (!have_last && can_improve_at_offset(bubble.bubble_exit, tmin, current, prev, next, mde)) return true;
         if ((!have_last || last_offset < tmax) &&
             can_improve_at_offset(bubble.bubble_exit, tmax, current, prev, next, mde)) return true;
-        if (prev && st == ST_I) {
+        if (prev && (st == ST_I || st == ST_I2)) {   // reached.rs:165-186
             Score c = visited.get_score({bubble.bubble_exit, *prev}, ST_M);
-            if (score_add(c, costs.gap_open) > current) return true;
+            if (score_add(c, st == ST_I ? costs.gap_open : costs.gap_open2) > current) return true;
         }
         return false;
     }

@@ -535,6 +535,25 @@ extern "C" int oracle_tie_census(void* p, uint8_t m, uint8_t o, uint8_t e, int h
     } catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
 }
 
+// Same for the two-piece model (inside oracle_set_two_piece(1, ...)): the five planes M, I1, D1, I2, D2.
+extern "C" int oracle_astar_table2(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, const uint8_t* seq,
+                                   uint64_t len, uint32_t* const* planes, uint64_t* out) {
+    auto* h = (GraphHandle*)p;
+    try {
+        Aligner A(h->g, h->bi(), mk_costs(m, o, e), (Heuristic)heuristic, prune != 0);
+        apply_aln_type(A);
+        AstarResult r = A.astar_alignment(seq, len);
+        const size_t n = h->g.symbol.size(), P = len + 1;
+        const AlignState order[5] = {ST_M, ST_I, ST_D, ST_I2, ST_D2};
+        for (int pl = 0; pl < 5; ++pl)
+            for (uint32_t v = 0; v < n; ++v)
+                for (uint32_t j = 0; j <= len; ++j) planes[pl][v * P + j] = A.visited.get_score({v, j}, order[pl]);
+        out[0] = r.score; out[1] = r.num_queued; out[2] = r.num_visited; out[3] = r.num_pruned;
+        return 0;
+    } catch (const RefPanic& ex) { g_last_error = ex.what(); return 1; }
+    catch (const std::exception& ex) { g_last_error = ex.what(); return -1; }
+}
+
 // The reference's visited table after one alignment, dense by NODE: M/I/D [node][len+1], UNVISITED = 0xFFFFFFFF.
 extern "C" int oracle_astar_table(void* p, uint8_t m, uint8_t o, uint8_t e, int heuristic, int prune, const uint8_t* seq,
                                   uint64_t len, uint32_t* pm, uint32_t* pi, uint32_t* pd, uint64_t* out) {

@@ -19,7 +19,7 @@ FLAG_AMBIGUOUS, FLAG_START_QUIRK, FLAG_REF_PANIC, FLAG_SHORT_QUERY, FLAG_TRUNCAT
 
 # every symbol include/poasta_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = ["poa_version", "poa_last_error", "poa_device_count", "poa_graph_create", "poa_graph_destroy",
-           "poa_graph_rows", "poa_graph_node_rows", "poa_graph_update", "poa_align_batch", "poa_align_batch_ex", "poa_align_batch_2piece", "poa_planes_2piece", "poa_release_cache", "poa_batch_create", "poa_batch_run",
+           "poa_graph_rows", "poa_graph_node_rows", "poa_graph_update", "poa_align_batch", "poa_align_batch_ex", "poa_align_batch_2piece", "poa_align_batch_2piece_ex", "poa_planes_2piece", "poa_release_cache", "poa_batch_create", "poa_batch_run",
            "poa_batch_run_ex",
            "poa_batch_fetch", "poa_batch_stats", "poa_batch_device_results", "poa_batch_fetch_search_counters", "poa_batch_last_layout", "poa_batch_fetch_planes", "poa_batch_destroy"]
 
@@ -136,6 +136,9 @@ def lib():
     L.poa_align_batch_2piece.restype = C.c_int
     L.poa_align_batch_2piece.argtypes = [vp, C.POINTER(PoaCosts2), C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp,
                                          C.POINTER(PoaStats), C.c_int]
+    L.poa_align_batch_2piece_ex.restype = C.c_int
+    L.poa_align_batch_2piece_ex.argtypes = [vp, C.POINTER(PoaCosts2), C.POINTER(PoaConfig), C.c_uint32, vp, vp, vp, vp, vp, C.c_uint64, vp,
+                                            C.POINTER(PoaStats), vp, C.c_int]
     L.poa_planes_2piece.restype = C.c_int
     L.poa_planes_2piece.argtypes = [vp, C.POINTER(PoaCosts2), vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_int]
     L.poa_batch_run_ex.restype = C.c_int

@@ -98,6 +98,17 @@ class Affine2PieceDijkstra:
         self.costs = costs
 
 
+class Affine2PieceMinGapCost:
+    """config.rs:215-272 — what `poasta align -g o1,o2 -e e1,e2` constructs (src/bin/poasta.rs:319-445).  Its results are
+    those of the reference's SEARCH (min-gap heuristic over a gap_cost that charges the open cost again inside a gap,
+    pruning): run it with `PoastaAligner(config, aln_type, mode="exact")`."""
+    heuristic = _lib.HEURISTIC_MINGAP
+    two_piece = True
+
+    def __init__(self, costs):
+        self.costs = costs
+
+
 class Bound:
     """std::ops::Bound<usize> as the reference's AlignmentType::EndsFree uses it."""
     Unbounded = (_lib.BOUND_UNBOUNDED, 0)
@@ -403,13 +414,24 @@ class PoastaAligner:
         st = _lib.PoaStats()
         c = self.config.costs._c()
         if getattr(self.config, "two_piece", False):
-            if self.aln_type != AlignmentType.Global or self.mode != "dense":
-                raise ValueError("the two-piece model runs as the dense Global pass")
-            _lib.check(_lib.lib().poa_align_batch_2piece(dg.handle, C.byref(c), n, _p(qseq), _p(qoff), _p(score), _p(pairs),
-                                                         _p(pair_off), cap, _p(flags), C.byref(st), self.device))
+            if self.mode == "dense":
+                if self.aln_type != AlignmentType.Global:
+                    raise ValueError("two-piece model: ends-free alignment runs as the exact replay (mode='exact')")
+                _lib.check(_lib.lib().poa_align_batch_2piece(dg.handle, C.byref(c), n, _p(qseq), _p(qoff), _p(score), _p(pairs),
+                                                             _p(pair_off), cap, _p(flags), C.byref(st), self.device))
+                counters = None
+            else:
+                # the reference's own search, five states (gap_affine_2piece.rs): scores and alignments are what it returns
+                cfg = make_config(self.mode, self.config.heuristic, pruning, self.queue_entries_per_cell, aln_type=self.aln_type)
+                counters = np.zeros((n, 4), np.uint32)
+                _lib.check(_lib.lib().poa_align_batch_2piece_ex(dg.handle, C.byref(c), C.byref(cfg), n, _p(qseq), _p(qoff), _p(score),
+                                                                _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), _p(counters),
+                                                                self.device))
             if want_pairs:
                 pairs = pairs[:int(pair_off[n])]
-            return BatchResult(score, pairs, pair_off, flags, st.as_dict())
+            res = BatchResult(score, pairs, pair_off, flags, st.as_dict())
+            res.search_counters = counters   # num_queued, num_visited, num_pruned, live queue entries (exact mode)
+            return res
         cfg = make_config(self.mode, self.config.heuristic, pruning, self.queue_entries_per_cell, aln_type=self.aln_type)
         _lib.check(_lib.lib().poa_align_batch_ex(dg.handle, C.byref(c), C.byref(cfg), n, _p(qseq), _p(qoff), _p(score),
                                                  _p(pairs), _p(pair_off), cap, _p(flags), C.byref(st), self.device))

@@ -1310,10 +1310,19 @@ void poa_release_cache(void) {
 // ---- two-piece affine model (poa_twopiece.hpp) ---------------------------------------------------------------------------
 namespace {
 // planes_out: null, or five host pointers (M, I1, D1, I2, D2) receiving the planes of query 0, rows x (len + 1)
-int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_queries, const uint8_t* qseq, const uint64_t* qoff,
-                  uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity, uint32_t* flags,
-                  poa_stats_t* stats, int device, uint32_t* const* planes_out) {
+int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, const poa_config_t* cfg, uint32_t n_queries, const uint8_t* qseq,
+                  const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off, uint64_t pair_capacity, uint32_t* flags,
+                  poa_stats_t* stats, int device, uint32_t* const* planes_out, uint32_t* counters_out) {
     if (!g || !costs || (n_queries && (!qseq || !qoff))) return fail(POA_ERR_INVALID_ARG, "poa_align_batch_2piece: null argument");
+    // mode: DENSE = the dense Global pass; EXACT / HYBRID = the replay of the reference's search for EVERY query (under this
+    // model a dense flag of 0 certifies the alignment only where the reference's search is optimal, and it need not be:
+    // DESIGN.md §6a — so there is no cheaper hybrid)
+    const bool exact = cfg && cfg->mode != POA_MODE_DENSE;
+    if (cfg && cfg->mode > POA_MODE_HYBRID) return fail(POA_ERR_INVALID_ARG, "poa_align_batch_2piece_ex: unknown mode");
+    if (cfg && cfg->span > POA_SPAN_ENDS_FREE) return fail(POA_ERR_INVALID_ARG, "poa_align_batch_2piece_ex: unknown alignment span");
+    const bool ends_free = cfg && cfg->span == POA_SPAN_ENDS_FREE;
+    if (ends_free && !exact) return fail(POA_ERR_UNSUPPORTED, "two-piece model: ends-free alignment needs the exact replay (mode EXACT)");
+    const TuneView T(cfg);
     if (costs->gap_extend1 < costs->gap_extend2)
         return fail(POA_ERR_INVALID_ARG, "gap_extend1 must be greater than or equal to gap_extend2 for two-piece model");
     if (poa_device_count() <= 0) return fail(POA_ERR_NO_DEVICE, "no HIP device: the engine has no CPU alignment path");
@@ -1340,17 +1349,41 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     const uint32_t pitch = (uint32_t)((max_len + 64) & ~63ull);
     const uint64_t per_query = 5ull * fg.n * pitch;   // plane elements
     if (per_query >= (1ull << 34)) return fail(POA_ERR_UNSUPPORTED, "two-piece pass: planes of one query too large");
+    if (exact && per_query >= (1ull << 32)) return fail(POA_ERR_UNSUPPORTED, "two-piece replay: the visited table of one query exceeds 2^32 cells");
     // u16 planes under the bound of the one-piece pass (poa_batch_run_ex) taken with the first piece's costs: a gap never
     // costs more than its first-piece price, so [o1 + e1 L] + [o1 + e1 (shortest path)] bounds the optimum here too
     const uint64_t ub = (max_len ? (uint64_t)costs->gap_open1 + (uint64_t)costs->gap_extend1 * max_len : 0) +
                         (fg.min_path_nodes ? (uint64_t)costs->gap_open1 + (uint64_t)costs->gap_extend1 * fg.min_path_nodes : 0);
     bool narrow = ub <= 65534;
-    if (costs->wide_planes) narrow = false;
+    if (costs->wide_planes || exact) narrow = false;   // (the replayed table is u32)
     const uint64_t elem = narrow ? 2 : 4;
+    // replay workspace per query slot (prepare_exact's sizes with five stacks per priority; the pool holds the entries live
+    // at once — popped slots are reused — at cfg->queue_entries_per_cell entries per cell, default 0.5)
+    uint32_t x_n_prio = 0, x_pool_cap = 0, x_stack_cap = 0, x_wpn = 0, x_swpn = 0;
+    uint64_t x_bytes = 0;
+    if (exact) {
+        std::string err;
+        int brc;
+        {
+            std::lock_guard<std::mutex> lk(const_cast<poa_graph*>(g)->bubble_mu);
+            brc = build_bubble_index(const_cast<FlatGraph&>(fg), err);
+        }
+        if (brc != POA_OK) return fail(brc, err);
+        const uint32_t om = std::max<uint32_t>(costs->gap_open1, costs->gap_open2);
+        const uint32_t maxc = std::max<uint32_t>(costs->mismatch, om + costs->gap_extend1);
+        const uint64_t n_prio64 = ((uint64_t)fg.n + max_len + 2) * maxc + 2ull * (om + ((uint64_t)fg.n + max_len) * costs->gap_extend1) + 64;
+        if (n_prio64 > (1ull << 26)) return fail(POA_ERR_UNSUPPORTED, "two-piece replay: priority range too large for this graph / query size");
+        const float f = (cfg->queue_entries_per_cell > 0.f) ? cfg->queue_entries_per_cell : 0.5f;
+        const uint64_t pool64 = std::max<uint64_t>(1024, (uint64_t)(f * (double)fg.n * (double)(max_len + 1)));
+        if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "two-piece replay: queue pool too large");
+        x_n_prio = (uint32_t)n_prio64; x_pool_cap = (uint32_t)pool64; x_stack_cap = (uint32_t)(fg.n + max_len + 8);
+        x_wpn = (uint32_t)((max_len + 1 + 63) / 64); x_swpn = (x_wpn + 63) / 64;
+        x_bytes = (uint64_t)fg.n_exit * (x_wpn + x_swpn) * 8 + 5ull * x_n_prio * 4 + (uint64_t)x_stack_cap * 12 + (uint64_t)x_pool_cap * 16;
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget = std::min<uint64_t>((uint64_t)(free_b * 0.6), 64ull << 30);
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_queries, budget / (per_query * elem + 1)));
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_queries, budget / (per_query * elem + x_bytes + 1)));
     const uint32_t stride = (uint32_t)std::min<uint64_t>(fg.n + max_len + 1, 0xFFFFFFFFull);
     DevBuf<RowMeta> d_rows; DevBuf<uint32_t> d_pred, d_planes, d_score, d_flags, d_np; DevBuf<uint8_t> d_q; DevBuf<uint64_t> d_qoff;
     DevBuf<poa_aln_pair_t> d_scratch;
@@ -1359,6 +1392,48 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     HIP_TRY(d_score.alloc(n_queries)); HIP_TRY(d_flags.alloc(n_queries)); HIP_TRY(d_np.alloc(n_queries));
     if (d_planes.alloc((size_t)((chunk * per_query * elem + 3) / 4)) != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, "two-piece pass: plane workspace");
     HIP_TRY(d_scratch.alloc((size_t)chunk * stride));
+    // the replay's view of the graph and its workspace
+    DevBuf<uint32_t> x_succ_off, x_succ, x_dmin, x_dmax, x_exit, x_nbm_off, x_node_row, x_sp, x_head, x_status, x_end, x_counters;
+    DevBuf<uint8_t> x_sym; DevBuf<FlatGraph::NodeBubble> x_nbm; DevBuf<uint64_t> x_reached, x_rsum;
+    DevBuf<ExQEntry> x_pool; DevBuf<ExStackEntry> x_stack;
+    TwoPieceExact X;
+    if (exact) {
+        const uint32_t n = fg.n;
+        HIP_TRY(x_succ_off.alloc(fg.succ_row_off.size())); HIP_TRY(x_succ.alloc(std::max<size_t>(fg.succ_rows.size(), 1)));
+        HIP_TRY(x_dmin.alloc(n)); HIP_TRY(x_dmax.alloc(n)); HIP_TRY(x_exit.alloc(n)); HIP_TRY(x_nbm_off.alloc(n + 1));
+        HIP_TRY(x_nbm.alloc(std::max<size_t>(fg.nbm.size(), 1))); HIP_TRY(x_node_row.alloc(n)); HIP_TRY(x_sp.alloc(n)); HIP_TRY(x_sym.alloc((size_t)n + 4));
+        std::vector<uint8_t> row_sym((size_t)n + 4, 0);
+        for (uint32_t r = 0; r < n; ++r) row_sym[r] = fg.rows[r].sym;
+        HIP_TRY(hipMemcpy(x_sym.p, row_sym.data(), row_sym.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_succ_off.p, fg.succ_row_off.data(), fg.succ_row_off.size() * 4, hipMemcpyHostToDevice));
+        if (!fg.succ_rows.empty()) HIP_TRY(hipMemcpy(x_succ.p, fg.succ_rows.data(), fg.succ_rows.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_dmin.p, fg.dist_min.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_dmax.p, fg.dist_max.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_exit.p, fg.exit_idx.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_nbm_off.p, fg.nbm_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+        if (!fg.nbm.empty()) HIP_TRY(hipMemcpy(x_nbm.p, fg.nbm.data(), fg.nbm.size() * sizeof(FlatGraph::NodeBubble), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_node_row.p, fg.node_row.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(x_sp.p, fg.sp_to_end.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(x_reached.alloc(std::max<uint64_t>((uint64_t)chunk * fg.n_exit * x_wpn, 1)));
+        HIP_TRY(x_rsum.alloc(std::max<uint64_t>((uint64_t)chunk * fg.n_exit * x_swpn, 1)));
+        HIP_TRY(x_head.alloc((size_t)chunk * 5 * x_n_prio)); HIP_TRY(x_stack.alloc((size_t)chunk * x_stack_cap));
+        if (x_pool.alloc((size_t)chunk * x_pool_cap) != hipSuccess) return fail(POA_ERR_OUT_OF_MEMORY, "two-piece replay: queue pool");
+        HIP_TRY(x_status.alloc(n_queries)); HIP_TRY(x_end.alloc(2 * (size_t)n_queries)); HIP_TRY(x_counters.alloc(4 * (size_t)n_queries));
+        X.G = ExactGraph{n, fg.start_row, fg.end_row, x_sym.p, x_succ_off.p, x_succ.p, x_dmin.p, x_dmax.p, x_exit.p, fg.n_exit,
+                         x_nbm_off.p, x_nbm.p, x_node_row.p, x_sp.p, nullptr};
+        X.C = ExactCosts{costs->mismatch, costs->gap_open1, costs->gap_extend1, cfg->heuristic, cfg->pruning, 0, 0, 0, 0, 0, 0,
+                         costs->gap_open2, costs->gap_extend2};
+        if (ends_free) {
+            X.C.ends_free = 1;
+            X.C.qfe_kind = cfg->qry_free_end.kind; X.C.qfe_val = cfg->qry_free_end.value;
+            X.C.gfb_kind = cfg->graph_free_begin.kind;
+            X.C.gfe_kind = cfg->graph_free_end.kind; X.C.gfe_val = cfg->graph_free_end.value;
+        }
+        X.reached = x_reached.p; X.rsum = x_rsum.p; X.wpn = x_wpn; X.swpn = x_swpn;
+        X.head = x_head.p; X.n_prio = x_n_prio; X.pool = x_pool.p; X.pool_cap = x_pool_cap;
+        X.stack = x_stack.p; X.stack_cap = x_stack_cap;
+        X.status = x_status.p; X.end_cell = x_end.p; X.counters = x_counters.p;
+    }
     HIP_TRY(hipMemcpy(d_rows.p, fg.rows.data(), fg.rows.size() * sizeof(RowMeta), hipMemcpyHostToDevice));
     if (!fg.pred_rows.empty()) HIP_TRY(hipMemcpy(d_pred.p, fg.pred_rows.data(), fg.pred_rows.size() * 4, hipMemcpyHostToDevice));
     if (qoff[n_queries]) HIP_TRY(hipMemcpy(d_q.p, qseq, qoff[n_queries], hipMemcpyHostToDevice));
@@ -1368,6 +1443,7 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
     P.qseq = d_q.p; P.qoff = d_qoff.p; P.pitch = pitch; P.planes = d_planes.p;
     P.x = costs->mismatch; P.o1 = costs->gap_open1; P.e1 = costs->gap_extend1; P.e2 = costs->gap_extend2; P.oe = (uint32_t)costs->gap_open1 + costs->gap_extend1;
     P.score = d_score.p; P.flags = d_flags.p; P.n_pairs = d_np.p; P.scratch = d_scratch.p; P.scratch_stride = stride;
+    P.exact_pass = exact ? 1u : 0u; P.ex_status = x_status.p; P.ex_end = x_end.p;
     struct Events {   // destroyed on every way out
         hipEvent_t e[3] = {nullptr, nullptr, nullptr};
         ~Events() { for (auto ev : e) if (ev) (void)hipEventDestroy(ev); }
@@ -1384,8 +1460,24 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
         const uint32_t cnt = std::min(chunk, n_queries - first);
         P.first_query = first; P.n_queries = cnt;
         HIP_TRY(hipEventRecord(e0, nullptr));
+        if (exact) {
+            // the search fills its table from nothing: unvisited planes, empty stacks, empty reached sets
+            HIP_TRY(hipMemsetAsync(d_planes.p, 0xFF, (size_t)cnt * per_query * 4, nullptr));
+            HIP_TRY(hipMemsetAsync(x_head.p, 0xFF, (size_t)cnt * 5 * x_n_prio * 4, nullptr));
+            if (fg.n_exit) {
+                HIP_TRY(hipMemsetAsync(x_reached.p, 0, (size_t)cnt * fg.n_exit * x_wpn * 8, nullptr));
+                HIP_TRY(hipMemsetAsync(x_rsum.p, 0, (size_t)cnt * fg.n_exit * x_swpn * 8, nullptr));
+            }
+            // active lanes per wave: enough waves to fill the chip first (one divergent search per lane), then more lanes
+            uint32_t lanes = (cnt + 4095) / 4096;
+            if (lanes > 64) lanes = 64;
+            if (const int* lv = T.ptr(POA_TUNE_EXACT_LANES)) { const int v = (*lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
+            X.lanes_per_wave = lanes;
+            const uint32_t per_block = lanes * 4;
+            hipLaunchKernelGGL(poa2_exact_kernel, dim3((cnt + per_block - 1) / per_block), dim3(256), 0, nullptr, P, X);
+        }
         // previous row in registers for up to 1024 (u16: two passes of 512) / 1024 (u32: four passes of 256) columns
-        if (narrow) hipLaunchKernelGGL((poa2_forward_kernel<uint16_t, 2>), dim3(cnt), dim3(64), 0, nullptr, P);
+        else if (narrow) hipLaunchKernelGGL((poa2_forward_kernel<uint16_t, 2>), dim3(cnt), dim3(64), 0, nullptr, P);
         else hipLaunchKernelGGL((poa2_forward_kernel<uint32_t, 4>), dim3(cnt), dim3(64), 0, nullptr, P);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
@@ -1429,6 +1521,7 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
         }
     }
     if (score) HIP_TRY(hipMemcpy(score, d_score.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+    if (exact && counters_out) HIP_TRY(hipMemcpy(counters_out, x_counters.p, (size_t)n_queries * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_flags.data(), d_flags.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
     if (flags) std::memcpy(flags, h_flags.data(), (size_t)n_queries * 4);
     if (stats) {
@@ -1437,6 +1530,7 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
         uint32_t nf = 0;
         for (uint32_t i = 0; i < n_queries; ++i) nf += h_flags[i] != 0;
         stats->n_flagged = nf;
+        if (exact) { stats->n_exact = n_queries; stats->ms_exact = ms_f; stats->ms_forward = 0; }
     }
     return rc;
 }
@@ -1445,7 +1539,13 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_qu
 int poa_align_batch_2piece(const poa_graph_t* g, const poa_costs2_t* costs, uint32_t n_queries, const uint8_t* qseq,
                            const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
                            uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, int device) {
-    return run_two_piece(g, costs, n_queries, qseq, qoff, score, pairs, pair_off, pair_capacity, flags, stats, device, nullptr);
+    return run_two_piece(g, costs, nullptr, n_queries, qseq, qoff, score, pairs, pair_off, pair_capacity, flags, stats, device, nullptr, nullptr);
+}
+
+int poa_align_batch_2piece_ex(const poa_graph_t* g, const poa_costs2_t* costs, const poa_config_t* cfg, uint32_t n_queries,
+                              const uint8_t* qseq, const uint64_t* qoff, uint32_t* score, poa_aln_pair_t* pairs, uint64_t* pair_off,
+                              uint64_t pair_capacity, uint32_t* flags, poa_stats_t* stats, uint32_t* search_counters, int device) {
+    return run_two_piece(g, costs, cfg, n_queries, qseq, qoff, score, pairs, pair_off, pair_capacity, flags, stats, device, nullptr, search_counters);
 }
 
 int poa_planes_2piece(const poa_graph_t* g, const poa_costs2_t* costs, const uint8_t* seq, uint32_t len, uint32_t* m,
@@ -1454,5 +1554,5 @@ int poa_planes_2piece(const poa_graph_t* g, const poa_costs2_t* costs, const uin
     const uint64_t qoff[2] = {0, len};
     uint32_t* out[5] = {m, i1, d1, i2, d2};
     uint32_t sc = 0, fl = 0;
-    return run_two_piece(g, costs, 1, seq, qoff, &sc, nullptr, nullptr, 0, &fl, nullptr, device, out);
+    return run_two_piece(g, costs, nullptr, 1, seq, qoff, &sc, nullptr, nullptr, 0, &fl, nullptr, device, out, nullptr);
 }

@@ -35,7 +35,7 @@
 
 namespace poa_amd {
 
-enum : uint32_t { EX_ST_M = 0, EX_ST_D = 1, EX_ST_I = 2 };
+enum : uint32_t { EX_ST_M = 0, EX_ST_D = 1, EX_ST_I = 2, EX_ST_D2 = 3, EX_ST_I2 = 4 };   // aln_graph.rs:8-14 (the last two: two-piece model)
 enum : uint32_t { EX_H_DIJKSTRA = 0, EX_H_MINGAP = 1 };
 enum : uint32_t {
     EX_OK = 0,
@@ -104,6 +104,8 @@ struct ExactCosts {
     uint32_t qfe_kind, qfe_val;   // qry_free_end
     uint32_t gfb_kind;            // graph_free_begin (only Unbounded-or-not matters, gap_affine.rs:150-167)
     uint32_t gfe_kind, gfe_val;   // graph_free_end
+    // GapAffine2Piece (gap_affine_2piece.rs:19-33): o / e above are the first piece, these the second (EX_AS_TWO_PIECE only)
+    uint32_t o2 = 0, e2 = 0;
 };
 
 // ---- speculative ("log") mode of the search object: the step of the wave kernel poa_psearch.hpp ----------------------------
@@ -151,7 +153,8 @@ struct SpecLane {
 // that may be global or LDS compiles to FLAT loads, which wait for every outstanding vector-memory AND LDS operation
 // (they count on both counters): one such load in the middle of a batch of table reads serialises the batch.  With the
 // tag the access is a ds_read / ds_write and overlaps with the global loads in flight.
-enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4, EX_AS_REC_LDS = 8 };   // (4: logs and read sets of the log mode: SpecLane::w_*, m_*, rc, rm_*)
+enum : int { EX_AS_GRAPH_LDS = 1, EX_AS_RING_LDS = 2, EX_AS_READSET_LDS = 4, EX_AS_REC_LDS = 8,
+             EX_AS_NO_SPEC = 16, EX_AS_TWO_PIECE = 32 };   // (32: the two-piece affine model, gap_affine_2piece.rs — five states, five plain planes, the generic code only)  (16: this instantiation never runs in log mode — the kernels of rounds 1 and 2: the log-mode branches compile away)   // (4: logs and read sets of the log mode: SpecLane::w_*, m_*, rc, rm_*)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T> __device__ inline __attribute__((always_inline)) T ex_lds_load(const T* p) {
     return *(const __attribute__((address_space(3))) T*)p;
@@ -203,7 +206,7 @@ public:
     ExactCosts C;
     uint32_t err = EX_OK;
     // queue state (queue.rs:19-22)
-    uint32_t layer_min = 0, n_layers = 0, pool_top = 0;
+    uint32_t layer_min = 0, n_layers = 0, pool_top = 0, pool_free = EX_NIL;
     uint32_t num_queued = 0, num_visited = 0, num_pruned = 0;
 
     POA_HD ExactSearchT(const ExactGraph& g, ExactWork& w, const uint8_t* s, uint32_t len, ExactCosts c)
@@ -212,13 +215,16 @@ public:
     // a search object is reused for the next query of its wave / lane group
     POA_HD void begin_query(const uint8_t* s, uint32_t len) {
         seq = s; L = len; err = EX_OK;
-        layer_min = 0; n_layers = 0; pool_top = 0; num_queued = num_visited = num_pruned = 0;
+        layer_min = 0; n_layers = 0; pool_top = 0; pool_free = EX_NIL; num_queued = num_visited = num_pruned = 0;
         bq_live = 0; bq_chunk_top = 0; bq_hi = 0; bq_free = EX_NIL;
         sp = 0; dfa_visited = 0; dfa_score = 0; n_fast = 0; num_pruned_dfa = 0;
     }
     // ---- log mode (see SpecLane) ---------------------------------------------------------------
     bool spec = false;
     SpecLane sl;
+    static constexpr bool TP = (AS & EX_AS_TWO_PIECE) != 0;
+    static constexpr uint32_t NST = TP ? 5u : 3u;   // states (planes of the table, stacks per priority)
+    POA_HD bool in_spec() const { if constexpr ((AS & EX_AS_NO_SPEC) != 0) return false; else return spec; }
 #if defined(POA_PS_PROF_FINE)
     unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = 0;
 #endif
@@ -261,18 +267,24 @@ public:
         for (uint32_t k = 0; k < sl.n_w; ++k) if (sld(&sl.w_idx[k * sl.stride]) == ix) v = sld(&sl.w_val[k * sl.stride]);
         return v;
     }
-    POA_HD uint32_t cix(uint32_t row, uint32_t off, uint32_t st) const { return ex_cell_index32(row, off, st, W.n_rows, W.pitch); }
+    POA_HD uint32_t cix(uint32_t row, uint32_t off, uint32_t st) const {
+        if constexpr (TP) {
+            // five plain planes in the order the two-piece traceback reads them (poa_twopiece.hpp): M, I1, D1, I2, D2
+            const uint32_t pl = st == EX_ST_M ? 0u : st == EX_ST_I ? 1u : st == EX_ST_D ? 2u : st == EX_ST_I2 ? 3u : 4u;
+            return (pl * W.n_rows + row) * W.pitch + off;
+        } else return ex_cell_index32(row, off, st, W.n_rows, W.pitch);
+    }
     // visited score of a cell inside the table
     POA_HD uint32_t ld(uint32_t row, uint32_t off, uint32_t st) {
         const uint32_t ix = cix(row, off, st);
         uint32_t v = W.T[ix];
-        if (spec) { note_cell(ix); if (sl.n_w) v = ovl(ix, v); }
+        if (in_spec()) { note_cell(ix); if (sl.n_w) v = ovl(ix, v); }
         return v;
     }
     POA_HD void wr(uint32_t row, uint32_t off, uint32_t st, uint32_t val) {
         const uint32_t ix = cix(row, off, st);
         EX_TRACE_CELL(row, off, st, 1);
-        if (!spec) { W.T[ix] = val; return; }
+        if (!in_spec()) { W.T[ix] = val; return; }
         // (append only — a later entry for the same cell wins, in the overlay and at the commit — so that the log can be cut back)
         if (sl.n_w >= SP_KW) { sp_flag(SPF_COMPLEX, 3); return; }
         sst(&sl.w_idx[sl.n_w * sl.stride], ix); sst(&sl.w_val[sl.n_w * sl.stride], val);
@@ -286,9 +298,9 @@ public:
     mutable uint64_t rc_w = 0, rs_w = 0;
     POA_HD uint64_t rword(uint32_t x, uint32_t wi) const {
         uint64_t w;
-        if (spec && rc_x == x && rc_wi == wi) w = rc_w;
-        else { w = W.reached[(uint64_t)x * W.wpn + wi]; if (spec) { rc_x = x; rc_wi = wi; rc_w = w; } }
-        if (spec && (sl.mmask & sp_bit(x))) for (uint32_t k = 0; k < sl.n_m; ++k) {
+        if (in_spec() && rc_x == x && rc_wi == wi) w = rc_w;
+        else { w = W.reached[(uint64_t)x * W.wpn + wi]; if (in_spec()) { rc_x = x; rc_wi = wi; rc_w = w; } }
+        if (in_spec() && (sl.mmask & sp_bit(x))) for (uint32_t k = 0; k < sl.n_m; ++k) {
             const uint32_t o = sld(&sl.m_off[k * sl.stride]);
             if (sld(&sl.m_x[k * sl.stride]) == x && (o >> 6) == wi) w |= 1ull << (o & 63);
         }
@@ -296,9 +308,9 @@ public:
     }
     POA_HD uint64_t rsw(uint32_t x, uint32_t si) const {
         uint64_t w;
-        if (spec && rs_x == x && rs_si == si) w = rs_w;
-        else { w = W.rsum[(uint64_t)x * W.swpn + si]; if (spec) { rs_x = x; rs_si = si; rs_w = w; } }
-        if (spec && (sl.mmask & sp_bit(x))) for (uint32_t k = 0; k < sl.n_m; ++k) {
+        if (in_spec() && rs_x == x && rs_si == si) w = rs_w;
+        else { w = W.rsum[(uint64_t)x * W.swpn + si]; if (in_spec()) { rs_x = x; rs_si = si; rs_w = w; } }
+        if (in_spec() && (sl.mmask & sp_bit(x))) for (uint32_t k = 0; k < sl.n_m; ++k) {
             const uint32_t o = sld(&sl.m_off[k * sl.stride]);
             if (sld(&sl.m_x[k * sl.stride]) == x && (o >> 12) == si) w |= 1ull << ((o >> 6) & 63);
         }
@@ -315,6 +327,12 @@ public:
     }
     POA_HD uint32_t gap_cost(uint32_t st, uint32_t length) const {  // gap_affine.rs:68-80
         if (length == 0) return 0;
+        if constexpr (TP) {   // gap_affine_2piece.rs:99-127 (sic: a state inside a gap is charged its open cost again)
+            const uint32_t c1 = C.o + length * C.e, c2 = C.o2 + length * C.e2;
+            if (st == EX_ST_I || st == EX_ST_D) return c1;
+            if (st == EX_ST_I2 || st == EX_ST_D2) return c2;
+            return c1 < c2 ? c1 : c2;
+        }
         return (st == EX_ST_M ? C.o : 0u) + length * C.e;
     }
     POA_HD bool is_symbol_equal(uint32_t row, uint8_t c) const {  // graphs/poa.rs:463-465
@@ -324,7 +342,7 @@ public:
     // ---- visited table (gap_affine.rs:483-548) -----------------------------------------------
     POA_HD uint32_t* cell(uint32_t row, uint32_t off, uint32_t st) const {
         // (a query's table has 3 * n_rows * pitch < 2^32 elements: the engine plans the workspace in 32-bit element counts per query)
-        return W.T + ex_cell_index32(row, off, st, W.n_rows, W.pitch);
+        return W.T + cix(row, off, st);
     }
     // Offsets beyond the row: the reference's table is a hash of tiles and takes any offset — an ends-free search that is
     // not allowed to stop at the query end opens an insertion at offset len + 1 (expand_ref_graph_end has no bound,
@@ -358,7 +376,7 @@ public:
         if (x == EX_NIL) return;
         if ((off >> 6) >= W.wpn) { err = EX_POOL_FULL; return; }
         EX_TRACE_REACH(row, off, off, 1);
-        if (!spec) { mark_word(x, off); return; }
+        if (!in_spec()) { mark_word(x, off); return; }
         if (sl.mmask & sp_bit(x)) for (uint32_t k = 0; k < sl.n_m; ++k) if (sld(&sl.m_x[k * sl.stride]) == x && sld(&sl.m_off[k * sl.stride]) == off) return;
         if (sl.n_m >= SP_KM) { sp_flag(SPF_COMPLEX, 4); return; }
         sst(&sl.m_x[sl.n_m * sl.stride], x); sst(&sl.m_off[sl.n_m * sl.stride], off);
@@ -369,14 +387,14 @@ public:
         const uint32_t x = gld(&G.exit_idx[row]);
         for (uint32_t i = 0; i < W.swpn; ++i) if (rsw(x, i)) return true;
         EX_TRACE_REACH(row, 0, 0xFFFFFFFFu, 0);
-        if (spec) note_marks(x, 0, 0xFFFFFFFFu);   // (any mark on this row would change the answer)
+        if (in_spec()) note_marks(x, 0, 0xFFFFFFFFu);   // (any mark on this row would change the answer)
         return false;
     }
     // largest reached offset < t, or EX_NIL  (row must be an exit row)
     POA_HD uint32_t reached_before(uint32_t row, uint32_t t) {
         const uint32_t r = reached_before_(row, t);
         EX_TRACE_REACH(row, r == EX_NIL ? 0u : r, t ? t - 1 : 0u, 0);
-        if (spec && t) note_marks(gld(&G.exit_idx[row]), r == EX_NIL ? 0u : r, t - 1);
+        if (in_spec() && t) note_marks(gld(&G.exit_idx[row]), r == EX_NIL ? 0u : r, t - 1);
         return r;
     }
     POA_HD uint32_t reached_before_(uint32_t row, uint32_t t) const {
@@ -405,7 +423,7 @@ public:
     POA_HD uint32_t reached_from(uint32_t row, uint32_t t) {
         const uint32_t r = reached_from_(row, t);
         EX_TRACE_REACH(row, t, r, 0);
-        if (spec) note_marks(gld(&G.exit_idx[row]), t, r);   // (EX_NIL: everything from t on)
+        if (in_spec()) note_marks(gld(&G.exit_idx[row]), t, r);   // (EX_NIL: everything from t on)
         return r;
     }
     POA_HD uint32_t reached_from_(uint32_t row, uint32_t t) const {
@@ -495,13 +513,13 @@ public:
         for (uint32_t next = reached_from(ex, tmin); next != EX_NIL && next <= tmax; next = reached_from(ex, next + 1)) {
             uint32_t offset1 = tmin;
             if (prev != EX_NIL) { const uint32_t pv = prev + 1u; offset1 = tmin > pv ? tmin : pv; }
-            if (st == EX_ST_D) {
+            if (st == EX_ST_D || (TP && st == EX_ST_D2)) {   // reached.rs:84-101
                 const uint32_t cst = get_score(ex, next, EX_ST_M);
-                if (score_add(cst, C.o) > current) return true;
+                if (score_add(cst, st == EX_ST_D ? C.o : C.o2) > current) return true;
             }
-            if (prev != EX_NIL && st == EX_ST_I) {
+            if (prev != EX_NIL && (st == EX_ST_I || (TP && st == EX_ST_I2))) {   // reached.rs:104-124
                 const uint32_t cst = get_score(ex, prev, EX_ST_M);
-                if (score_add(cst, C.o) > current) return true;
+                if (score_add(cst, st == EX_ST_I ? C.o : C.o2) > current) return true;
             }
             if (can_improve_at_offset(ex, offset1, current, prev, next, mde)) return true;
             const uint32_t nm1 = next - 1u;  // wrapping u32 subtraction, as in a release build
@@ -517,9 +535,9 @@ public:
         const uint32_t nxt = reached_from(ex, from);
         if (!have_last && can_improve_at_offset(ex, tmin, current, prev, nxt, mde)) return true;
         if ((!have_last || last_offset < tmax) && can_improve_at_offset(ex, tmax, current, prev, nxt, mde)) return true;
-        if (prev != EX_NIL && st == EX_ST_I) {
+        if (prev != EX_NIL && (st == EX_ST_I || (TP && st == EX_ST_I2))) {   // reached.rs:165-186
             const uint32_t cst = get_score(ex, prev, EX_ST_M);
-            if (score_add(cst, C.o) > current) return true;
+            if (score_add(cst, st == EX_ST_I ? C.o : C.o2) > current) return true;
         }
         return false;
     }
@@ -602,15 +620,19 @@ public:
     POA_HD void queue_state(uint32_t row, uint32_t off, uint32_t st, uint32_t new_score) {
         const uint32_t pr64 = new_score + h(row, off, st);
         num_queued += 1;
-        if (spec) { spec_queue(pr64, st, new_score, row, off); return; }
+        if (in_spec()) { spec_queue(pr64, st, new_score, row, off); return; }
         if (W.bq_desc) { bq_push(pr64, st, new_score, row, off); return; }
-        if (pr64 >= W.n_prio || pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; }
+        if (pr64 >= W.n_prio) { err = EX_POOL_FULL; return; }
+        // a popped entry's slot is reused (free list threaded through `next`): the pool holds the entries that are LIVE at
+        // once, not every entry ever queued (a cell is queued again each time its score drops)
+        uint32_t e;
+        if (pool_free != EX_NIL) { e = pool_free; pool_free = W.pool[e].next; }
+        else { if (pool_top >= W.pool_cap) { err = EX_POOL_FULL; return; } e = pool_top++; }
         const uint32_t prio = pr64;
         if (n_layers == 0) { n_layers = 1; layer_min = prio; }
         else if (prio < layer_min) { n_layers += layer_min - prio; layer_min = prio; }
         else if (prio >= layer_min + n_layers) { n_layers = prio - layer_min + 1; }
-        const uint32_t e = pool_top++;
-        uint32_t* hd = &W.head[3 * (uint64_t)prio + st];
+        uint32_t* hd = &W.head[NST * (uint64_t)prio + stack_slot(st)];
         W.pool[e] = ExQEntry{new_score, row, off, *hd};
         *hd = e;
     }
@@ -654,19 +676,28 @@ public:
         sl.n_pd -= 1;
         return true;
     }
+    // Pop order of the stacks of a priority: Match, Deletion, Insertion (gap_affine.rs:954-966); two-piece: Match, Deletion,
+    // Deletion2, Insertion, Insertion2 (gap_affine_2piece.rs:1069-1097).  The table below maps a state to its stack and back.
+    static POA_HD uint32_t stack_slot(uint32_t st) {
+        if constexpr (TP) return st == EX_ST_I ? 3u : st == EX_ST_D2 ? 2u : st;
+        else return st;
+    }
     POA_HD bool layer_empty(uint32_t prio) const {
-        const uint32_t* hd = &W.head[3 * (uint64_t)prio];
-        return hd[0] == EX_NIL && hd[1] == EX_NIL && hd[2] == EX_NIL;
+        const uint32_t* hd = &W.head[NST * (uint64_t)prio];
+        for (uint32_t s = 0; s < NST; ++s) if (hd[s] != EX_NIL) return false;
+        return true;
     }
     POA_HD bool pop_state(uint32_t& score, uint32_t& row, uint32_t& off, uint32_t& st) {
         if (n_layers == 0) return false;
-        uint32_t* hd = &W.head[3 * (uint64_t)layer_min];
+        uint32_t* hd = &W.head[NST * (uint64_t)layer_min];
         bool got = false;
-        for (uint32_t s = 0; s < 3; ++s) {  // Match stack, else Deletion, else Insertion (state codes 0,1,2)
+        for (uint32_t s = 0; s < NST; ++s) {  // the stacks in pop order (stack_slot is its own inverse)
             if (hd[s] != EX_NIL) {
-                const ExQEntry e = W.pool[hd[s]];
+                const uint32_t ix = hd[s];
+                const ExQEntry e = W.pool[ix];
                 hd[s] = e.next;
-                score = e.score; row = e.row; off = e.offset; st = s;
+                W.pool[ix].next = pool_free; pool_free = ix;
+                score = e.score; row = e.row; off = e.offset; st = stack_slot(s);
                 got = true;
                 break;
             }
@@ -681,7 +712,8 @@ public:
     POA_HD bool is_end(uint32_t row, uint32_t off, uint32_t st) const {  // gap_affine.rs:185-248
         if (!C.ends_free) return st == EX_ST_M && row == G.end_row && off == L;
         bool q_ok;
-        if (C.qfe_kind == EX_BOUND_UNBOUNDED) q_ok = off > 0 || L == 0;  // sic: any consumed prefix may end
+        if (C.qfe_kind == EX_BOUND_UNBOUNDED) q_ok = TP ? (off >= L || L == 0)       // gap_affine_2piece.rs:246-250
+                                                          : (off > 0 || L == 0);     // sic: any consumed prefix may end
         else if (C.qfe_kind == EX_BOUND_INCLUDED) q_ok = L - off <= C.qfe_val;
         else q_ok = L - off < C.qfe_val;
         // dist_to_end(node, max) (gap_affine.rs:91-119) finds the end iff the shortest path has <= max edges
@@ -719,7 +751,7 @@ public:
         EX_TRACE_CELL(crow, coff, EX_ST_M, 0); EX_TRACE_CELL(prow, poff + 1, EX_ST_I, 0); EX_TRACE_CELL(crow, poff, EX_ST_D, 0);
         const uint32_t im = cix(crow, coff, EX_ST_M), ii = cix(prow, poff + 1, EX_ST_I), id = cix(crow, poff, EX_ST_D);
         uint32_t vm = W.T[im], vi = W.T[ii], vd = W.T[id];
-        if (spec) {
+        if (in_spec()) {
             note_cell(im); note_cell(ii); note_cell(id);
             if (sl.n_w) { vm = ovl(im, vm); vi = ovl(ii, vi); vd = ovl(id, vd); }
         }
@@ -729,6 +761,24 @@ public:
     }
     POA_HD void expand_all(uint32_t score, uint32_t row, uint32_t off, uint32_t st) {
         if (update_if_lower(row, off, EX_ST_M, score)) queue_state(row, off, EX_ST_M, score);
+        if constexpr (TP) {
+            // gap_affine_2piece.rs:346-431: a state of the first piece extends in its piece (extend1) and moves to the second
+            // (extend2); a state of the second piece extends there; open2 is never charged
+            const uint32_t n1 = score_add(score, C.e), n2 = score_add(score, C.e2);
+            if (err) return;
+            if (st == EX_ST_I || st == EX_ST_I2) {
+                if (st == EX_ST_I && off < L && update_if_lower(row, off + 1, EX_ST_I, n1)) queue_state(row, off + 1, EX_ST_I, n1);
+                if (off < L && update_if_lower(row, off + 1, EX_ST_I2, n2)) queue_state(row, off + 1, EX_ST_I2, n2);
+            } else {
+                for (uint32_t e = gld(&G.succ_off[row]); e < gld(&G.succ_off[row + 1]); ++e) {
+                    const uint32_t c = gld(&G.succ[e]);
+                    if (st == EX_ST_D && update_if_lower(c, off, EX_ST_D, n1)) queue_state(c, off, EX_ST_D, n1);
+                    if (update_if_lower(c, off, EX_ST_D2, n2)) queue_state(c, off, EX_ST_D2, n2);
+                    if (err) return;
+                }
+            }
+            return;
+        }
         if (st == EX_ST_I) {
             const uint32_t ns = score_add(score, C.e);
             if (err) return;
@@ -760,14 +810,18 @@ public:
     }
     POA_HD void dfa_push(uint32_t row, uint32_t off, bool parent_exhausted) {
         if (!parent_exhausted) {
-            if (spec) {   // (the stack in memory is the query's; a lane keeps a few entries of its own)
+            if (in_spec()) {   // (the stack in memory is the query's; a lane keeps a few entries of its own)
                 if (sp - 1 >= SP_KDS) { sp_flag(SPF_COMPLEX, 7); return; }
                 sl.dstack[(sp - 1) * sl.stride] = dfa_top;
                 sp += 1;
                 dfa_top = ExStackEntry{row, off, gld(&G.succ_off[row])};
                 return;
             }
-            if (sp >= W.stack_cap) { err = EX_POOL_FULL; return; }
+            // (a select, not a store under a branch: the optimiser otherwise merges that store with the one to dfa_top
+            // below into one store through a pointer phi, and both members then live in scratch memory)
+            const bool full = sp >= W.stack_cap;
+            err = full ? (uint32_t)EX_POOL_FULL : err;
+            if (full) return;
             W.stack[sp - 1] = dfa_top;
             sp += 1;
         }
@@ -775,7 +829,7 @@ public:
     }
     POA_HD void dfa_pop() {
         sp -= 1;
-        if (sp != 0) dfa_top = spec ? sl.dstack[(sp - 1) * sl.stride] : W.stack[sp - 1];
+        if (sp != 0) dfa_top = in_spec() ? sl.dstack[(sp - 1) * sl.stride] : W.stack[sp - 1];
     }
 
     POA_HD Event dfa_extend() {
@@ -791,7 +845,7 @@ public:
             }
         }
         while (sp != 0) {
-            if (spec && (sl.flags & SPF_COMPLEX)) break;
+            if (in_spec() && (sl.flags & SPF_COMPLEX)) break;
             ExStackEntry& parent = dfa_top;
             const uint32_t cend = gld(&G.succ_off[parent.row + 1]);
             bool again = false;
@@ -884,13 +938,13 @@ public:
         const uint32_t va = W.T[ia], vb = W.T[ib], vc = W.T[ic];
         if (P.t) P.ta = va;
         P.tb = vb; P.tc = vc;
-        if (spec && sl.n_w) { if (P.t) P.ta = ovl(ia, va); P.tb = ovl(ib, vb); P.tc = ovl(ic, vc); }
+        if (in_spec() && sl.n_w) { if (P.t) P.ta = ovl(ia, va); P.tb = ovl(ib, vb); P.tc = ovl(ic, vc); }
     }
     // 0: can improve (not pruned); 2: pruned; 3: something the generic code has to look at (a reached cell without a score).
     // reached.rs:38-255 specialised to tmin == tmax.
     POA_HD uint32_t probe_decide(const Probe& P, uint32_t g, uint32_t st) {
         if (!P.on) return 0;                        // no bubble to test
-        if (P.sum == 0) { if (spec) note_marks(gld(&G.exit_idx[P.ex]), 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
+        if (P.sum == 0) { if (in_spec()) note_marks(gld(&G.exit_idx[P.ex]), 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
         const uint32_t t = P.t, wi = P.wi, ex = P.ex;
         uint32_t prev = EX_NIL, nxt = EX_NIL;
         const bool at_t = (P.w1 >> (t & 63)) & 1;
@@ -908,7 +962,7 @@ public:
 #endif
         // what the decision read of the exit row: the marks between the two neighbours and the scores at them (reached at t:
         // the neighbour above is not looked at, reached.rs:139)
-        if (spec) {
+        if (in_spec()) {
             note_marks(gld(&G.exit_idx[ex]), prev == EX_NIL ? 0u : prev, at_t ? t : nxt);
             if (prev != EX_NIL && prev < W.pitch) note_cell(cix(ex, prev, EX_ST_M));
             if (at_t) note_cell(cix(ex, t, EX_ST_M));
@@ -917,7 +971,7 @@ public:
         // scores of the two neighbours: next to t they are loaded already; else both loads go out together
         const uint32_t iq = cix(ex, prev != EX_NIL && prev < W.pitch ? prev : t, EX_ST_M), jq = cix(ex, nxt != EX_NIL && nxt < W.pitch ? nxt : t, EX_ST_M);
         uint32_t lq = W.T[iq], rq = W.T[jq];
-        if (spec && sl.n_w) { lq = ovl(iq, lq); rq = ovl(jq, rq); }
+        if (in_spec() && sl.n_w) { lq = ovl(iq, lq); rq = ovl(jq, rq); }
         uint32_t ls = 0, rs = 0;
         if (prev != EX_NIL) ls = prev + 1 == t ? P.ta : lq;
         if (nxt != EX_NIL) rs = nxt == t + 1 ? P.tc : (nxt < W.pitch ? rq : EX_INF);
@@ -961,6 +1015,7 @@ public:
     // generic code).
     POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
         F.kind = 0;
+        if constexpr (TP) return 3;   // (two-piece model: the generic code)
         const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
         const uint32_t ns = s1 - s0;
         // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341)
@@ -979,6 +1034,7 @@ public:
         }
         Probe P, Q;
         const bool probes = probe_setup(v, j, P, Q, true);
+        if constexpr ((AS & EX_AS_NO_SPEC) != 0) { if (!probes) { EXD(3, st); return 3; } }   // (wave kernels: the generic code takes it, nothing loaded twice)
         // ---- every load of the step, before any use ----
         const uint32_t i_own = cix(v, j, st);
         uint32_t i0, i1, i2 = i_own, i3 = i_own, i4 = i_own;
@@ -989,7 +1045,7 @@ public:
         uint32_t t0 = W.T[i0], t1 = W.T[i1], t2 = st == EX_ST_M ? W.T[i2] : EX_INF;
         uint32_t t3 = c1 != EX_NIL ? W.T[i3] : EX_INF, t4 = (c1 != EX_NIL && st == EX_ST_M) ? W.T[i4] : EX_INF;
         if (probes) { probe_load(P); probe_load(Q); }
-        if (spec) {
+        if (in_spec()) {
             // (the probes note what they looked at when they decide)
             note_cell(i_own); note_cell(i0); if (st != EX_ST_I || j < L) note_cell(i1); if (st == EX_ST_M) note_cell(i2);
             if (c1 != EX_NIL) { note_cell(i3); if (st == EX_ST_M) note_cell(i4); }
@@ -1002,6 +1058,7 @@ public:
         n_fast += 1;
         if (g > own) return 1;                      // stale (astar.rs:146)
         uint32_t r = probes ? probe_decide2(P, Q, g, st) : 3u;
+        if constexpr ((AS & EX_AS_NO_SPEC) != 0) { if (r == 3) { EXD(probes ? 5 : 3, st); return 3; } }   // (wave kernel: the entry's own lane takes the generic code after the run)
         if (r == 3) { PF_TICK(1); r = (C.prune && prune(g, v, j, st)) ? 2u : 0u; PF_TICK(5); }   // bubbles of another shape: the generic test (astar.rs:155)
         if (err) return 3;
         EXD(r == 0 ? (kind == 2 ? 7 : 6) : 0, st);
@@ -1045,7 +1102,7 @@ public:
         for (;;) {
             // here: cc is a successor of the row before, not the end row, cj < L, sym(cc) == seq[cj]
             const uint32_t nj = cj + 1;
-            if (spec && (sl.flags & SPF_COMPLEX)) break;   // (the lane is cut off: whatever it does from here on is discarded)
+            if (in_spec() && (sl.flags & SPF_COMPLEX)) break;   // (the lane is cut off: whatever it does from here on is discarded)
             if (!(g < tm)) break;                          // already there with this score or better: not extended (dfa.rs:242)
             wr(cc, nj, EX_ST_M, g);
             // what the tip needs next: its own successor, its bubble test, and what a mismatch there relaxes
@@ -1059,7 +1116,7 @@ public:
             if (walk_on) {
                 const uint32_t j0 = cix(nc, nj + 1, EX_ST_M), j1 = cix(cc, nj + 1, EX_ST_I), j2 = cix(nc, nj, EX_ST_D);
                 n0 = W.T[j0]; n1 = W.T[j1]; n2 = W.T[j2];
-                if (spec) {
+                if (in_spec()) {
                     note_cell(j0); note_cell(j1); note_cell(j2);
                     if (sl.n_w) { n0 = ovl(j0, n0); n1 = ovl(j1, n1); n2 = ovl(j2, n2); }
                 }
@@ -1348,10 +1405,13 @@ public:
     }
     POA_HD void lp_load3(LProbe& P) const {
         // scores at the two neighbours: next to the range they are loaded already
-        if (P.prev != EX_NIL) { if (P.prev + 1 == P.tmin) P.sp = P.cw[0]; else if (P.prev < W.pitch) P.sp = W.T[cix(P.e, P.prev, EX_ST_M)]; }
+        // (the members are read before any branch: loads in the arms of a conditional get merged into one load through a
+        // selected ADDRESS, and a probe whose address is taken lives in scratch memory, every member of it)
+        const uint32_t c0 = P.cw[0], c2 = P.cw[2], c3 = P.cw[3], c4 = P.cw[4];
+        if (P.prev != EX_NIL) { if (P.prev + 1 == P.tmin) P.sp = c0; else if (P.prev < W.pitch) P.sp = W.T[cix(P.e, P.prev, EX_ST_M)]; }
         if (P.nxt != EX_NIL) {
             const uint32_t wd = P.tmax - P.tmin;
-            if (P.nxt == P.tmax + 1) P.sn = wd == 0 ? P.cw[2] : wd == 1 ? P.cw[3] : P.cw[4];
+            if (P.nxt == P.tmax + 1) P.sn = wd == 0 ? c2 : wd == 1 ? c3 : c4;
             else if (P.nxt < W.pitch) P.sn = W.T[cix(P.e, P.nxt, EX_ST_M)];
         }
     }
@@ -1369,8 +1429,8 @@ public:
     // what the reference would.  Notes what the decision depended on.
     POA_HD uint32_t lp_decide(const LProbe& P, uint32_t g, uint32_t st) {
         if (!P.on) return 0;
-        if (P.S == 0) { if (spec) note_marks(P.x, 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
-        if (spec) {
+        if (P.S == 0) { if (in_spec()) note_marks(P.x, 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
+        if (in_spec()) {
             note_marks(P.x, P.prev == EX_NIL ? 0u : P.prev, P.nxt);
             if (P.prev != EX_NIL && P.prev < W.pitch) note_cell(cix(P.e, P.prev, EX_ST_M));
             if (P.nxt != EX_NIL && P.nxt < W.pitch) note_cell(cix(P.e, P.nxt, EX_ST_M));
@@ -1386,7 +1446,7 @@ public:
             const uint64_t wd = (next >> 6) == (P.tmin >> 6) ? P.W0 : P.W1;
             if (!((wd >> (next & 63)) & 1)) continue;
             const uint32_t ns = P.cw[k + 1];
-            if (spec) note_cell(cix(P.e, next, EX_ST_M));
+            if (in_spec()) note_cell(cix(P.e, next, EX_ST_M));
             if (ns == EX_INF) return 3;
             const uint32_t offset1 = prev != EX_NIL ? (P.tmin > prev + 1 ? P.tmin : prev + 1) : P.tmin;
             if (st == EX_ST_D && ns + C.o > g) return 0;
@@ -1465,7 +1525,7 @@ public:
         lp_load3(P0); lp_load3(P1); lp_load3(Q0); lp_load3(Q1);
         PF_TICK(3);
         // ---- decisions ----
-        if (spec) {
+        if (in_spec()) {
             if (!cont) note_cell(i_own);
             if (est == EX_ST_M) {
                 if (q < L) { if (k0 == 0) { note_cell(iA); note_cell(iC); } note_cell(iB); if (c1 != EX_NIL) { note_cell(iD); note_cell(iE); } }

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(EXACT_BLOCK) void poa_exact_kernel(ExactParams P) {
     W.pool_cap = P.pool_cap;
     W.stack = P.stack + (uint64_t)slot * P.stack_cap;
     W.stack_cap = P.stack_cap;
-    ExactSearch S(G, W, P.qseq + qbeg, L, P.C);
+    ExactSearchT<EX_AS_NO_SPEC> S(G, W, P.qseq + qbeg, L, P.C);
     const ExactResult R = S.run();
     P.status[qi] = R.status;
     P.end_cell[2 * qi] = R.end_row;

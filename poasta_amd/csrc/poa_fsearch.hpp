@@ -81,11 +81,11 @@ constexpr uint32_t PS_ALL_WORDS = 0xFFFFFFu;   // "some word of this exit's set"
 struct FsFallbackIO {
     ExactGraph G; ExactWork W; const uint8_t* seq; uint32_t L; ExactCosts C;
     uint32_t layer_min, bq_live, bq_hi, bq_chunk_top, bq_free, err;     // queue state, in / out
-    uint32_t walk_on; ExactSearchT<0>::LeanWalk wk; ExU4 e; uint32_t st;  // what: the extension wk, or the entry e of state st
+    uint32_t walk_on; ExactSearchT<EX_AS_NO_SPEC>::LeanWalk wk; ExU4 e; uint32_t st;  // what: the extension wk, or the entry e of state st
     uint32_t found, end_score, end_row, end_off, dq, dv, dp;              // out: end of the search; counters to add
 };
 __device__ __attribute__((noinline)) void fs_fallback(FsFallbackIO* io) {
-    ExactSearchT<0> S(io->G, io->W, io->seq, io->L, io->C);
+    ExactSearchT<EX_AS_NO_SPEC> S(io->G, io->W, io->seq, io->L, io->C);
     S.layer_min = io->layer_min; S.bq_live = io->bq_live; S.bq_hi = io->bq_hi; S.bq_chunk_top = io->bq_chunk_top; S.bq_free = io->bq_free;
     S.err = io->err; S.bq_wr = true;
     ExactResult R{EX_OK, EX_INF, 0, 0, 0, io->G.end_row, io->L};

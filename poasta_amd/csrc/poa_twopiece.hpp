@@ -38,7 +38,53 @@ struct TwoPieceParams {
     uint32_t* n_pairs;                 // [total]
     poa_aln_pair_t* scratch;           // per slot: n_rows + pitch pairs, written back to front
     uint32_t scratch_stride;
+    // replayed search (poa2_exact_kernel ran on u32 planes): where each walk starts and what became of the search
+    uint32_t exact_pass;
+    const uint32_t* ex_status;         // [total] EX_*
+    const uint32_t* ex_end;            // [2 * total] (row, offset) the search stopped at
 };
+
+// Replay of the reference's two-piece search (Affine2PieceMinGapCost / Affine2PieceDijkstra with or without pruning,
+// config.rs:160-272; astar.rs:124-226 over gap_affine_2piece.rs): the search object of poa_exact.hpp instantiated with
+// EX_AS_TWO_PIECE — the generic code, five plain u32 planes (the layout the traceback below reads), linked-list queue with
+// five stacks per priority in the reference's pop order.  One search per lane, `lanes_per_wave` lanes of a wave active.
+struct TwoPieceExact {
+    ExactGraph G;
+    ExactCosts C;
+    uint64_t* reached; uint64_t* rsum; uint32_t wpn, swpn;   // per slot: n_exit * wpn / n_exit * swpn words
+    uint32_t* head; uint32_t n_prio;                          // per slot: 5 * n_prio
+    ExQEntry* pool; uint32_t pool_cap;
+    ExStackEntry* stack; uint32_t stack_cap;
+    uint32_t* status;        // [total]
+    uint32_t* end_cell;      // [2 * total]
+    uint32_t* counters;      // [4 * total] num_queued, num_visited, num_pruned, queue entries live at once (high water)
+    uint32_t lanes_per_wave;
+};
+
+__global__ __launch_bounds__(256) void poa2_exact_kernel(TwoPieceParams P, TwoPieceExact X) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane >= X.lanes_per_wave) return;
+    const uint32_t slot = (blockIdx.x * 4 + wave) * X.lanes_per_wave + lane;
+    if (slot >= P.n_queries) return;
+    const uint32_t qi = P.first_query + slot;
+    const uint64_t qbeg = P.qoff[qi];
+    const uint32_t L = (uint32_t)(P.qoff[qi + 1] - qbeg);
+    ExactWork W;
+    W.T = P.planes + (uint64_t)slot * 5 * P.n_rows * P.pitch;
+    W.n_rows = P.n_rows; W.pitch = P.pitch;
+    W.reached = X.reached + (uint64_t)slot * X.G.n_exit * X.wpn;
+    W.rsum = X.rsum + (uint64_t)slot * X.G.n_exit * X.swpn;
+    W.wpn = X.wpn; W.swpn = X.swpn;
+    W.head = X.head + (uint64_t)slot * 5 * X.n_prio; W.n_prio = X.n_prio;
+    W.pool = X.pool + (uint64_t)slot * X.pool_cap; W.pool_cap = X.pool_cap;
+    W.stack = X.stack + (uint64_t)slot * X.stack_cap; W.stack_cap = X.stack_cap;
+    ExactSearchT<EX_AS_NO_SPEC | EX_AS_TWO_PIECE> S(X.G, W, P.qseq + qbeg, L, X.C);
+    const ExactResult R = S.run();
+    X.status[qi] = R.status;
+    X.end_cell[2 * qi] = R.end_row; X.end_cell[2 * qi + 1] = R.end_off;
+    X.counters[4 * qi] = R.num_queued; X.counters[4 * qi + 1] = R.num_visited; X.counters[4 * qi + 2] = R.num_pruned;
+    X.counters[4 * qi + 3] = S.pool_top;
+}
 
 __device__ __forceinline__ uint32_t tp_sat(uint32_t a, uint32_t b) {
     const uint32_t r = a + b;
@@ -212,10 +258,22 @@ __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
     uint32_t n_out = 0, fl = 0;
     auto emit = [&](uint32_t rpos, uint32_t qpos) { if (n_out < P.scratch_stride) out[P.scratch_stride - 1 - n_out] = poa_aln_pair_t{rpos, qpos}; n_out++; };
     auto sym_eq = [&](uint32_t row, uint8_t c) { return row == P.end_row || P.rows[row].sym == c; };
+    // the cell the walk starts from: (end row, L) in the dense Global pass; where the replayed search stopped otherwise
+    uint32_t tb_row = P.end_row, tb_off = L;
+    if (P.exact_pass) {
+        const uint32_t stt = P.ex_status[qi];
+        if (stt != 0) {   // the reference panics ("Could not align sequence!", a Score overflow) / the workspace ran out
+            P.flags[qi] = stt == 1 ? POA_FLAG_REF_PANIC : POA_FLAG_EXACT_OVERFLOW;
+            P.n_pairs[qi] = 0; P.score[qi] = 0xFFFFFFFFu;
+            return;
+        }
+        tb_row = P.ex_end[2 * qi]; tb_off = P.ex_end[2 * qi + 1];
+        P.score[qi] = S(tb_row, tb_off, SM);
+    }
     if (L == 0) { P.flags[qi] = 0; P.n_pairs[qi] = 0; return; }
-    if (L == 1) {   // gap_affine_2piece.rs:952-965: the end node equals every symbol
-        emit(P.rows[P.end_row].node, 0);
-        P.flags[qi] = POA_FLAG_SHORT_QUERY; P.n_pairs[qi] = 1;
+    if (L == 1 && tb_off == 1 && sym_eq(tb_row, q[0])) {   // gap_affine_2piece.rs:952-965 (Global: the end node equals every symbol)
+        emit(P.rows[tb_row].node, 0);
+        P.flags[qi] = P.exact_pass ? 0u : POA_FLAG_SHORT_QUERY; P.n_pairs[qi] = 1;
         return;
     }
     struct Step { uint32_t row, j, st; bool found; };
@@ -287,14 +345,14 @@ __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
         }
         return first;
     };
-    Step cur = step(P.end_row, L, SM);
+    Step cur = step(tb_row, tb_off, SM);
     bool dead = false;
     if (pn) { fl |= POA_FLAG_REF_PANIC | POA_FLAG_TRUNCATED; dead = true; }
     else if (cur.found && (nc != 1 || plt)) fl |= POA_FLAG_AMBIGUOUS;
     if (!dead && !cur.found) {
         const uint32_t order[4] = {SI, SI2, SD, SD2};   // gap_affine_2piece.rs:972-978
         for (int k = 0; k < 4 && !cur.found && !dead; ++k) {
-            cur = step(P.end_row, L, order[k]);
+            cur = step(tb_row, tb_off, order[k]);
             if (pn) { fl |= POA_FLAG_REF_PANIC | POA_FLAG_TRUNCATED; dead = true; }
         }
         if (!dead && !cur.found) { fl |= POA_FLAG_REF_PANIC; dead = true; }
@@ -318,7 +376,8 @@ __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
         }
         if (!reached_start) fl |= POA_FLAG_TRUNCATED;
     }
-    P.flags[qi] = fl;
+    // (a replayed table IS the reference's: its backtrace takes the first candidate, nothing to certify)
+    P.flags[qi] = P.exact_pass ? (fl & (POA_FLAG_REF_PANIC | POA_FLAG_TRUNCATED)) : fl;
     P.n_pairs[qi] = n_out;
 }
 

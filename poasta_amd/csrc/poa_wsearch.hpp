@@ -102,13 +102,13 @@ __device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
     // graph arrays and descriptor ring both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers
     const bool lds_all = P.graph_lds && !P.ring_global;
     if constexpr (!GROUPS) {
-        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS>(P, G, ring, lane, wave);
-        else ws_search_query<0>(P, G, ring, lane, wave);
+        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_NO_SPEC>(P, G, ring, lane, wave);
+        else ws_search_query<EX_AS_NO_SPEC>(P, G, ring, lane, wave);
     } else {
         // (the host asks for groups only with graph and rings in LDS)
-        if (P.group == 32) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 32>(P, G, ring, lane, wave);
-        else if (P.group == 16) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 16>(P, G, ring, lane, wave);
-        else ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS, 8>(P, G, ring, lane, wave);
+        if (P.group == 32) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_NO_SPEC, 32>(P, G, ring, lane, wave);
+        else if (P.group == 16) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_NO_SPEC, 16>(P, G, ring, lane, wave);
+        else ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_NO_SPEC, 8>(P, G, ring, lane, wave);
     }
 }
 

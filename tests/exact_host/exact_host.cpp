@@ -104,6 +104,50 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     return (int)R.status;
 }
 
+// Two-piece affine model (gap_affine_2piece.rs): the same search object instantiated with EX_AS_TWO_PIECE — generic code,
+// linked-list queue, five plain planes.  costs = (mismatch, open1, extend1, open2, extend2); planes (optional): M, I1, D1, I2, D2
+// as [node][len+1]; out[0..5] = score, num_queued, num_visited, num_pruned, end node, end offset.
+int exact_host_run2(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
+                    const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred, const uint8_t* costs5,
+                    int heuristic, int prune, const uint8_t* seq, uint32_t len, uint32_t* out, uint32_t* const* planes,
+                    const uint32_t* span) {
+    FlatGraph g;
+    std::string err;
+    int rc = build_flat_graph(n, start, end, symbol, succ_off, succ, pred_off, pred, g, err);
+    if (rc != POA_OK) return rc;
+    rc = build_bubble_index(g, err);
+    if (rc != POA_OK) return rc;
+    std::vector<uint8_t> row_sym(g.n);
+    for (uint32_t r = 0; r < g.n; ++r) row_sym[r] = g.rows[r].sym;
+    ExactGraph G{g.n, g.start_row, g.end_row, row_sym.data(), g.succ_row_off.data(), g.succ_rows.data(),
+                 g.dist_min.data(), g.dist_max.data(), g.exit_idx.data(), g.n_exit, g.nbm_off.data(), g.nbm.data(),
+                 g.node_row.data(), g.sp_to_end.data(), nullptr};
+    const uint32_t x = costs5[0], o1 = costs5[1], e1 = costs5[2], o2 = costs5[3], e2 = costs5[4];
+    const uint32_t pitch = ((len + 1 + 63) / 64) * 64, wpn = (len + 1 + 63) / 64, swpn = (wpn + 63) / 64;
+    std::vector<uint32_t> T((size_t)5 * n * pitch, EX_INF);
+    std::vector<uint64_t> reached((size_t)g.n_exit * wpn + 1, 0), rsum((size_t)g.n_exit * swpn + 1, 0);
+    const uint32_t om = std::max(o1, o2);
+    const uint32_t n_prio = (n + len + 2) * std::max<uint32_t>(x, om + e1) + 2 * (om + (n + len) * e1) + 64;
+    std::vector<uint32_t> head((size_t)5 * n_prio, EX_NIL);
+    std::vector<ExQEntry> pool((size_t)64 * n * (len + 1) + 1024);   // (a cell is queued again each time its score drops: often, under this model's inadmissible heuristic)
+    std::vector<ExStackEntry> stack(n + len + 8);
+    ExactWork W{T.data(), g.n, pitch, reached.data(), rsum.data(), wpn, swpn, head.data(), n_prio,
+                pool.data(), (uint32_t)pool.size(), stack.data(), (uint32_t)stack.size()};
+    ExactCosts EC{x, o1, e1, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0, o2, e2};
+    if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
+    ExactSearchT<EX_AS_NO_SPEC | EX_AS_TWO_PIECE> S(G, W, seq, len, EC);
+    const ExactResult R = S.run();
+    if (getenv("EXH_VERBOSE")) fprintf(stderr, "two-piece: status %u, pool %u of %zu, n_prio %u, layer_min %u + %u, queued %u\n", R.status, S.pool_top, pool.size(), n_prio, S.layer_min, S.n_layers, R.num_queued);
+    out[0] = R.score; out[1] = R.num_queued; out[2] = R.num_visited; out[3] = R.num_pruned;
+    out[4] = g.rows[R.end_row].node; out[5] = R.end_off;
+    if (planes) {
+        for (int pl = 0; pl < 5; ++pl)
+            for (uint32_t v = 0; v < n; ++v)
+                std::memcpy(planes[pl] + (size_t)v * (len + 1), T.data() + ((size_t)pl * n + g.node_row[v]) * pitch, ((size_t)len + 1) * 4);
+    }
+    return (int)R.status;
+}
+
 // bubble index of the product side, by NODE: dist (min,max), is_exit, node_bubble_map (exit node, min, max)
 int exact_host_bubbles(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symbol, const uint32_t* succ_off,
                        const uint32_t* succ, const uint32_t* pred_off, const uint32_t* pred, uint32_t* dmin, uint32_t* dmax,

@@ -33,6 +33,7 @@ def harness():
     X.exact_host_bubbles.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp] * 5 + [C.c_uint32]
     X.exact_host_set_batch.argtypes = [C.c_uint32]
     X.exact_host_set_parallel.argtypes = [C.c_uint32] * 3
+    X.exact_host_run2.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp]
     return X
 
 
@@ -97,6 +98,70 @@ def _compare(oracle, X, g, qs, costs, heur, prune, span=None):
         assert np.array_equal(om, xm) and np.array_equal(oi, xi) and np.array_equal(od, xd), "visited table"
         n_ok += 1
     return n_ok
+
+
+def _compare2(oracle, X, g, qs, costs5, heur, prune, span=None):
+    """Two-piece model (gap_affine_2piece.rs): costs5 = (mismatch, open1, extend1, open2, extend2).  The product's search
+    object instantiated with EX_AS_TWO_PIECE against the oracle's literal two-piece search: counters, end cell and all
+    five planes of the visited table."""
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    L = oracle.lib()
+    L.oracle_astar_table2.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8, C.c_int, C.c_int, vp, C.c_uint64, vp, vp]
+    sarr, ospec = _span_args(oracle, span)
+    x, o1, e1, o2, e2 = costs5
+    c5 = np.array(costs5, np.uint8)
+    n_ok = 0
+    for q in qs:
+        q = np.ascontiguousarray(q, np.uint8)
+        op = [np.zeros((g.n, len(q) + 1), np.uint32) for _ in range(5)]
+        xp = [np.zeros((g.n, len(q) + 1), np.uint32) for _ in range(5)]
+        optr = (vp * 5)(*[a.ctypes.data for a in op])
+        xptr = (vp * 5)(*[a.ctypes.data for a in xp])
+        oo = np.zeros(4, np.uint64)
+        with oracle.two_piece(o2, e2):
+            if ospec is None:
+                rc1 = L.oracle_astar_table2(og.h, x, o1, e1, heur, prune, _p(q), len(q), optr, _p(oo))
+            else:
+                with oracle.alignment_type(ospec):
+                    rc1 = L.oracle_astar_table2(og.h, x, o1, e1, heur, prune, _p(q), len(q), optr, _p(oo))
+        xo = np.zeros(6, np.uint32)
+        rc2 = X.exact_host_run2(g.n, g.start, g.end, _p(g.symbol), _p(g.succ_off), _p(g.succ), _p(g.pred_off), _p(g.pred),
+                                _p(c5), heur, prune, _p(q), len(q), _p(xo), xptr, _p(sarr) if sarr is not None else None)
+        if rc1 == 1 and rc2 == 0:
+            continue  # the oracle's panic came from the backtrace, which the search does not include
+        if rc1 == 1 and rc2 == 2:
+            n_ok += 1   # "Could not align sequence!" on both sides (EX_PANIC)
+            continue
+        assert rc1 == 0 and rc2 == 0, (rc1, rc2)
+        assert oo.tolist() == xo[:4].tolist(), "score / num_queued / num_visited / num_pruned"
+        for a, b in zip(op, xp):
+            assert np.array_equal(a, b), "visited table"
+        n_ok += 1
+    return n_ok
+
+
+def test_two_piece_replay_equals_oracle_search_cpu(oracle, harness):
+    """`poasta align -g 6,24 -e 2,1` builds Affine2PieceMinGapCost with pruning (config.rs:215-272): every heuristic /
+    pruning combination, random DAGs, ends-free spans; plus the structured workloads."""
+    n_ok = 0
+    for seed in range(60):
+        rng = np.random.Generator(np.random.PCG64(7000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        qs = [W.random_walk_query(rng, g, 0.3, alpha) for _ in range(6)]
+        costs5 = [(4, 6, 2, 24, 1), (1, 3, 12, 6, 1), (2, 8, 2, 12, 2), (3, 1, 1, 1, 1), (4, 4, 3, 10, 1)][seed % 5]
+        for heur, prune in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            n_ok += _compare2(oracle, harness, g, qs, costs5, heur, prune)
+        if seed % 3 == 0:
+            for span in (dict(qry_free_end=oracle.UNBOUNDED, graph_free_begin=oracle.UNBOUNDED, graph_free_end=oracle.UNBOUNDED),
+                         dict(qry_free_end=(oracle.INCLUDED, 2), graph_free_end=(oracle.EXCLUDED, 3)),
+                         dict(graph_free_begin=oracle.UNBOUNDED, graph_free_end=(oracle.INCLUDED, 1))):
+                n_ok += _compare2(oracle, harness, g, qs, costs5, 1, 1, span)
+    assert n_ok > 1300, n_ok
+    g, (qseq, qoff) = W.scaled_linearish(300, 15, 8, 16, 330)
+    assert _compare2(oracle, harness, g, [qseq[int(qoff[i]):int(qoff[i + 1])] for i in range(16)], (4, 6, 2, 24, 1), 1, 1) == 16
+    pg = W.PangenomePOA(ref_len=300, n_hap=6, p_snp=0.02, p_indel=0.01, max_indel=6, seed=4)
+    assert _compare2(oracle, harness, pg.graph, pg.queries(6, length=120), (4, 6, 2, 24, 1), 1, 1) == 6
 
 
 def test_product_bubble_index_matches_oracle(oracle, harness):

@@ -198,3 +198,79 @@ def test_gpu_two_piece_config2_sample(engine, oracle):
     # the one-piece model with open' = o1 + e1 - e2, extend' = e2 has the same optimum (a gap of k costs o1 + e1 + (k-1) e2)
     one = engine.PoastaAligner(engine.AffineMinGapCost(engine.GapAffine(4, 1, 7))).align_batch(g, qseq=qseq, qoff=qoff)
     assert np.array_equal(one.score, res.score)
+
+
+def _ef(engine, oracle, spec):
+    """(engine EndsFree, oracle ends_free spec) from a dict of oracle-style bounds."""
+    b = lambda v: engine.Bound.Unbounded if v == oracle.UNBOUNDED else (engine.Bound.Included(v[1]) if v[0] == oracle.INCLUDED else engine.Bound.Excluded(v[1]))
+    qfe, gfb, gfe = spec.get("qry_free_end", (oracle.INCLUDED, 0)), spec.get("graph_free_begin", (oracle.INCLUDED, 0)), spec.get("graph_free_end", (oracle.INCLUDED, 0))
+    return (engine.EndsFree(engine.Bound.Included(0), b(qfe), b(gfb), b(gfe)),
+            oracle.ends_free((oracle.INCLUDED, 0), qfe, gfb, gfe))
+
+
+@pytest.mark.gpu
+def test_gpu_two_piece_exact_replay_equals_the_search(engine, oracle):
+    """poa_align_batch_2piece_ex, mode EXACT: the reference's own two-piece search on the GPU (poa2_exact_kernel) — score,
+    alignment and the three search counters equal the oracle's literal search (oracle/astar.hpp, Costs::two_piece) for every
+    query, under every heuristic / pruning combination and ends-free spans; the search's score may exceed the dense optimum."""
+    n = n_above = n_panic = 0
+    for seed in range(36):
+        rng = np.random.Generator(np.random.PCG64(9000 + seed))
+        alpha = b"AC" if seed % 2 else b"ACGT"
+        g = W.random_dag(seed, n_nodes=int(rng.integers(3, 14)), p_edge=0.3, alphabet=alpha)
+        og = oracle.OracleGraph.from_csr(g.as_dict())
+        m, e1, o1, e2, o2 = COSTS2[seed % len(COSTS2)]
+        qs = [q for q in (W.random_walk_query(rng, g, 0.35, alpha) for _ in range(6)) if len(q) >= 1]
+        spans = [None]
+        if seed % 3 == 0:
+            spans += [dict(qry_free_end=oracle.UNBOUNDED, graph_free_begin=oracle.UNBOUNDED, graph_free_end=oracle.UNBOUNDED),
+                      dict(qry_free_end=(oracle.INCLUDED, 2), graph_free_end=(oracle.EXCLUDED, 3))]
+        for span in spans:
+            for cfgcls, heur in ((engine.Affine2PieceMinGapCost, oracle.H_MINGAP), (engine.Affine2PieceDijkstra, oracle.H_DIJKSTRA)):
+                for prune in (True, False):
+                    if span is None:
+                        aln_type, ospec = engine.AlignmentType.Global, None
+                    else:
+                        aln_type, ospec = _ef(engine, oracle, span)
+                    al = engine.PoastaAligner(cfgcls(engine.GapAffine2Piece(m, e1, o1, e2, o2)), aln_type, mode="exact")
+                    res = al.align_batch(g, qs, pruning=prune)
+                    dense = engine.PoastaAligner(engine.Affine2PieceDijkstra(engine.GapAffine2Piece(m, e1, o1, e2, o2))).align_batch(g, qs) if span is None else None
+                    for i, q in enumerate(qs):
+                        with oracle.two_piece(o2, e2):
+                            try:
+                                if ospec is None:
+                                    a = og.astar_align(q, oracle.Costs(m, o1, e1), heur, prune)
+                                else:
+                                    with oracle.alignment_type(ospec):
+                                        a = og.astar_align(q, oracle.Costs(m, o1, e1), heur, prune)
+                            except oracle.RefPanic:
+                                assert int(res.flags[i]) & (engine._lib.FLAG_REF_PANIC | engine._lib.FLAG_TRUNCATED), (seed, bytes(q))
+                                n_panic += 1
+                                continue
+                        assert int(res.flags[i]) & ~engine._lib.FLAG_TRUNCATED == 0, (seed, bytes(q), int(res.flags[i]))
+                        assert int(res.score[i]) == a["score"], (seed, bytes(q), span, heur, prune)
+                        assert res.raw_alignment(i) == a["alignment"], (seed, bytes(q), span, heur, prune)
+                        assert res.search_counters[i, :3].tolist() == [a["num_queued"], a["num_visited"], a["num_pruned"]]
+                        if dense is not None:
+                            assert int(res.score[i]) >= int(dense.score[i])
+                            n_above += int(res.score[i]) > int(dense.score[i])
+                        n += 1
+    assert n > 1000, n
+    assert n_above > 0   # DESIGN.md §6a: the literal search is not optimal under min-gap / pruning
+
+
+@pytest.mark.gpu
+def test_gpu_two_piece_exact_config2_sample(engine, oracle):
+    """configs[1] shape under `poasta align -g 6,24 -e 2,1` (Affine2PieceMinGapCost, pruning on, Global): every alignment
+    of a sample bit-identical to the oracle's search, several workspace chunks."""
+    g, (qseq, qoff) = W.config2(n_queries=24)
+    al = engine.PoastaAligner(engine.Affine2PieceMinGapCost(engine.GapAffine2Piece(4, 2, 6, 1, 24)), mode="exact")
+    res = al.align_batch(g, qseq=qseq, qoff=qoff)
+    og = oracle.OracleGraph.from_csr(g.as_dict())
+    with oracle.two_piece(24, 1):
+        A = og.astar_batch(qseq, qoff, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True, threads=8, want_counters=True)
+    assert not A["status"].any() and not res.flags.any()
+    assert np.array_equal(res.score, A["score"])
+    assert np.array_equal(res.search_counters[:, :3], A["counters"].astype(np.uint32))
+    for i in range(24):
+        assert res.raw_alignment(i) == oracle.batch_alignment(A, i)
