@@ -1382,7 +1382,8 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, const poa_con
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = std::min<uint64_t>((uint64_t)(free_b * 0.6), 64ull << 30);
+    // (the replay is bound by the latency of its dependent loads: as many searches in flight as the memory holds)
+    const uint64_t budget = exact ? (uint64_t)(free_b * 0.85) : std::min<uint64_t>((uint64_t)(free_b * 0.6), 64ull << 30);
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_queries, budget / (per_query * elem + x_bytes + 1)));
     const uint32_t stride = (uint32_t)std::min<uint64_t>(fg.n + max_len + 1, 0xFFFFFFFFull);
     DevBuf<RowMeta> d_rows; DevBuf<uint32_t> d_pred, d_planes, d_score, d_flags, d_np; DevBuf<uint8_t> d_q; DevBuf<uint64_t> d_qoff;
@@ -1469,12 +1470,20 @@ int run_two_piece(const poa_graph_t* g, const poa_costs2_t* costs, const poa_con
                 HIP_TRY(hipMemsetAsync(x_rsum.p, 0, (size_t)cnt * fg.n_exit * x_swpn * 8, nullptr));
             }
             // active lanes per wave: enough waves to fill the chip first (one divergent search per lane), then more lanes
-            uint32_t lanes = (cnt + 4095) / 4096;
+            uint32_t lanes = (cnt + 8191) / 8192;
             if (lanes > 64) lanes = 64;
             if (const int* lv = T.ptr(POA_TUNE_EXACT_LANES)) { const int v = (*lv); if (v >= 1 && v <= 64) lanes = (uint32_t)v; }
             X.lanes_per_wave = lanes;
-            const uint32_t per_block = lanes * 4;
-            hipLaunchKernelGGL(poa2_exact_kernel, dim3((cnt + per_block - 1) / per_block), dim3(256), 0, nullptr, P, X);
+            // graph arrays in LDS when they fit (one copy per block of 16 waves)
+            X.n_succ = (uint32_t)fg.succ_rows.size(); X.n_nbm = (uint32_t)fg.nbm.size();
+            const uint32_t lds_bytes = exact_lds_bytes(fg.n, X.n_succ, X.n_nbm);
+            bool lds_graph = lds_bytes <= 150u * 1024u;
+            if (const int* gv = T.ptr(POA_TUNE_EXACT_LDS)) lds_graph = lds_graph && (*gv) != 0;
+            if (lds_graph && lds_bytes > 48u * 1024u)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(poa2_exact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            X.lds_graph = lds_graph ? 1u : 0u;
+            const uint32_t per_block = lanes * (EXACT2_BLOCK / 64);
+            hipLaunchKernelGGL(poa2_exact_kernel, dim3((cnt + per_block - 1) / per_block), dim3(EXACT2_BLOCK), lds_graph ? lds_bytes : 0, nullptr, P, X);
         }
         // previous row in registers for up to 1024 (u16: two passes of 512) / 1024 (u32: four passes of 256) columns
         else if (narrow) hipLaunchKernelGGL((poa2_forward_kernel<uint16_t, 2>), dim3(cnt), dim3(64), 0, nullptr, P);

@@ -40,34 +40,37 @@ __host__ __device__ inline uint32_t exact_lds_bytes(uint32_t n_rows, uint32_t n_
            pad(sizeof(FlatGraph::NodeBubble) * (uint64_t)n_nbm);
 }
 
+// Every search of a block reads the same graph: stage its arrays in LDS once (latency, not bandwidth, bounds the search, and
+// an LDS read is an order of magnitude closer than an L2 hit).  All threads of the block call this; G receives the LDS
+// addresses (generic pointers), src holds the global ones.
+__device__ inline void exact_stage_graph(ExactGraph& G, const ExactGraph& src, uint8_t* lds, uint32_t n_succ, uint32_t n_nbm) {
+    uint32_t at = 0;
+    auto stage = [&](const void* from, uint64_t bytes) {
+        uint8_t* dst = lds + at;
+        const uint32_t words = (uint32_t)((bytes + 3) / 4);
+        const uint32_t* s32 = static_cast<const uint32_t*>(from);
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) reinterpret_cast<uint32_t*>(dst)[i] = s32[i];
+        at += (uint32_t)((bytes + 15) & ~15ull);
+        return dst;
+    };
+    const uint32_t n = src.n_rows;
+    G.sym = stage(src.sym, n);
+    G.succ_off = reinterpret_cast<const uint32_t*>(stage(src.succ_off, 4ull * (n + 1)));
+    G.nbm_off = reinterpret_cast<const uint32_t*>(stage(src.nbm_off, 4ull * (n + 1)));
+    G.succ = reinterpret_cast<const uint32_t*>(stage(src.succ, 4ull * n_succ));
+    G.dist_min = reinterpret_cast<const uint32_t*>(stage(src.dist_min, 4ull * n));
+    G.dist_max = reinterpret_cast<const uint32_t*>(stage(src.dist_max, 4ull * n));
+    G.exit_idx = reinterpret_cast<const uint32_t*>(stage(src.exit_idx, 4ull * n));
+    G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(src.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)n_nbm));
+    __syncthreads();
+}
+
 constexpr int EXACT_BLOCK = 256;  // 4 waves share one LDS copy of the graph
 
 __global__ __launch_bounds__(EXACT_BLOCK) void poa_exact_kernel(ExactParams P) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     ExactGraph G = P.G;
-    if (P.lds_graph) {
-        // every search of the block reads the same graph: stage its arrays in LDS once (latency, not bandwidth, bounds
-        // the search, and an LDS read is an order of magnitude closer than an L2 hit)
-        uint32_t at = 0;
-        auto stage = [&](const void* src, uint64_t bytes) {
-            uint8_t* dst = lds + at;
-            const uint32_t words = (uint32_t)((bytes + 3) / 4);
-            const uint32_t* s32 = static_cast<const uint32_t*>(src);
-            for (uint32_t i = threadIdx.x; i < words; i += EXACT_BLOCK) reinterpret_cast<uint32_t*>(dst)[i] = s32[i];
-            at += (uint32_t)((bytes + 15) & ~15ull);
-            return dst;
-        };
-        const uint32_t n = P.G.n_rows;
-        G.sym = stage(P.G.sym, n);
-        G.succ_off = reinterpret_cast<const uint32_t*>(stage(P.G.succ_off, 4ull * (n + 1)));
-        G.nbm_off = reinterpret_cast<const uint32_t*>(stage(P.G.nbm_off, 4ull * (n + 1)));
-        G.succ = reinterpret_cast<const uint32_t*>(stage(P.G.succ, 4ull * P.n_succ));
-        G.dist_min = reinterpret_cast<const uint32_t*>(stage(P.G.dist_min, 4ull * n));
-        G.dist_max = reinterpret_cast<const uint32_t*>(stage(P.G.dist_max, 4ull * n));
-        G.exit_idx = reinterpret_cast<const uint32_t*>(stage(P.G.exit_idx, 4ull * n));
-        G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(P.G.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)P.n_nbm));
-        __syncthreads();
-    }
+    if (P.lds_graph) exact_stage_graph(G, P.G, lds, P.n_succ, P.n_nbm);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane >= P.lanes_per_wave) return;
     const uint32_t slot = (blockIdx.x * (EXACT_BLOCK / 64) + wave) * P.lanes_per_wave + lane;

@@ -59,12 +59,17 @@ struct TwoPieceExact {
     uint32_t* end_cell;      // [2 * total]
     uint32_t* counters;      // [4 * total] num_queued, num_visited, num_pruned, queue entries live at once (high water)
     uint32_t lanes_per_wave;
+    uint32_t lds_graph, n_succ, n_nbm;   // 1: the launch carries exact_lds_bytes() of dynamic LDS for the graph arrays
 };
 
-__global__ __launch_bounds__(256) void poa2_exact_kernel(TwoPieceParams P, TwoPieceExact X) {
+constexpr int EXACT2_BLOCK = 1024;   // 16 waves share one LDS copy of the graph
+
+__global__ __launch_bounds__(EXACT2_BLOCK) void poa2_exact_kernel(TwoPieceParams P, TwoPieceExact X) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+    if (X.lds_graph) { const ExactGraph src = X.G; exact_stage_graph(X.G, src, lds2, X.n_succ, X.n_nbm); }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (lane >= X.lanes_per_wave) return;
-    const uint32_t slot = (blockIdx.x * 4 + wave) * X.lanes_per_wave + lane;
+    const uint32_t slot = (blockIdx.x * (EXACT2_BLOCK / 64) + wave) * X.lanes_per_wave + lane;
     if (slot >= P.n_queries) return;
     const uint32_t qi = P.first_query + slot;
     const uint64_t qbeg = P.qoff[qi];
