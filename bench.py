@@ -384,6 +384,10 @@ def main():
             line["bit_exact_value"] = be["value"]
             line["bit_exact_alignments_identical_fraction"] = round(be["alignments_identical"] / max(n_cpu, 1), 4)
             line["bit_exact_vs_cpu_baseline"] = round(be["value"] / line["cpu_baseline"]["value"], 2) if line["cpu_baseline"]["value"] else None
+            # (the main batch holds its replay workspace for 10 000 queries: released first, or the second batch would run in the
+            # memory that is left — several chunks, each as long as its longest search)
+            batch.close()
+            aligner._lib.lib().poa_release_cache()
             line["bit_exact_unpadded"] = bit_exact_unpadded(poa, graph, costs, stream, local_rank, args.queries, n_rows)
         print(json.dumps(line), flush=True)
     batch.close()

@@ -227,6 +227,21 @@ struct GapAffine {
     uint8_t gap_extend() const { return cost_gap_extend; }
 };
 
+// GapAffine2Piece::new(cost_mismatch, cost_gap_extend1, cost_gap_open1, cost_gap_extend2, cost_gap_open2) — the reference's
+// argument order; it panics unless extend1 >= extend2 (gap_affine_2piece.rs:28-33)
+struct GapAffine2Piece {
+    uint8_t cost_mismatch, cost_gap_extend1, cost_gap_open1, cost_gap_extend2, cost_gap_open2;
+    GapAffine2Piece(uint8_t mismatch, uint8_t gap_extend1, uint8_t gap_open1, uint8_t gap_extend2, uint8_t gap_open2)
+        : cost_mismatch(mismatch), cost_gap_extend1(gap_extend1), cost_gap_open1(gap_open1), cost_gap_extend2(gap_extend2), cost_gap_open2(gap_open2) {
+        if (gap_extend1 < gap_extend2) throw PoastaError("gap_extend1 must be greater than or equal to gap_extend2 for two-piece model");
+    }
+    uint8_t mismatch() const { return cost_mismatch; }
+    uint8_t gap_open() const { return cost_gap_open1; }
+    uint8_t gap_extend() const { return cost_gap_extend1; }
+    uint8_t gap_open2() const { return cost_gap_open2; }
+    uint8_t gap_extend2() const { return cost_gap_extend2; }
+};
+
 // std::ops::Bound<usize> and AlignmentType (scoring/mod.rs:50-62).  `AlignmentType::Global` or
 // `AlignmentType::EndsFree(qry_free_begin, qry_free_end, graph_free_begin, graph_free_end)`; an ends-free result is
 // defined by the reference's search, so the library replays that search for every query (exact mode implied).
@@ -247,8 +262,13 @@ struct AlignmentType {
 };
 inline const AlignmentType AlignmentType::Global{};
 
-struct AffineMinGapCost { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_MINGAP; explicit AffineMinGapCost(GapAffine c) : costs(c) {} };
-struct AffineDijkstra { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_DIJKSTRA; explicit AffineDijkstra(GapAffine c) : costs(c) {} };
+struct AffineMinGapCost { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_MINGAP; static constexpr bool two_piece = false; explicit AffineMinGapCost(GapAffine c) : costs(c) {} };
+struct AffineDijkstra { GapAffine costs; static constexpr uint32_t heuristic = POA_HEURISTIC_DIJKSTRA; static constexpr bool two_piece = false; explicit AffineDijkstra(GapAffine c) : costs(c) {} };
+// config.rs:160-272: what `poasta align -g o1,o2 -e e1,e2` constructs.  Mode::Dense (Global only) is the optimum of the model's
+// alignment graph; Mode::Exact / Hybrid replay the reference's own five-state search (poa_align_batch_2piece_ex), whose
+// score may exceed that optimum — the reference's result, tie-breaks included.
+struct Affine2PieceMinGapCost { GapAffine2Piece costs; static constexpr uint32_t heuristic = POA_HEURISTIC_MINGAP; static constexpr bool two_piece = true; explicit Affine2PieceMinGapCost(GapAffine2Piece c) : costs(c) {} };
+struct Affine2PieceDijkstra { GapAffine2Piece costs; static constexpr uint32_t heuristic = POA_HEURISTIC_DIJKSTRA; static constexpr bool two_piece = true; explicit Affine2PieceDijkstra(GapAffine2Piece c) : costs(c) {} };
 
 struct AstarResult {  // astar.rs:81-90 (+ the exactness certificate of the dense pass)
     uint32_t score = 0;
@@ -283,7 +303,6 @@ public:
         std::vector<uint32_t> score(n), flags(n);
         std::vector<uint64_t> pair_off(n + 1, 0);
         std::vector<poa_aln_pair_t> pairs(cap);
-        const poa_costs_t c{config_.costs.mismatch(), config_.costs.gap_open(), config_.costs.gap_extend(), 0};
         poa_config_t cfg{};
         cfg.mode = (uint32_t)mode_; cfg.heuristic = Config::heuristic; cfg.pruning = pruning ? 1u : 0u;
         if (aln_type_.ends_free) {
@@ -293,12 +312,25 @@ public:
             cfg.graph_free_begin = poa_bound_t{aln_type_.graph_free_begin.kind, aln_type_.graph_free_begin.value};
             cfg.graph_free_end = poa_bound_t{aln_type_.graph_free_end.kind, aln_type_.graph_free_end.value};
         }
-        const int rc = poa_align_batch_ex(g.device_graph(), &c, &cfg, n, (const uint8_t*)qseq.data(), qoff.data(), score.data(),
-                                          pairs.data(), pair_off.data(), cap, flags.data(), stats, device_);
+        std::vector<uint32_t> counters;
+        int rc;
+        if constexpr (Config::two_piece) {
+            poa_costs2_t c{};
+            c.mismatch = config_.costs.mismatch(); c.gap_open1 = config_.costs.gap_open(); c.gap_extend1 = config_.costs.gap_extend();
+            c.gap_open2 = config_.costs.gap_open2(); c.gap_extend2 = config_.costs.gap_extend2();
+            if (mode_ != Mode::Dense || aln_type_.ends_free) { cfg.mode = POA_MODE_EXACT; counters.resize(4 * (size_t)n); }
+            rc = poa_align_batch_2piece_ex(g.device_graph(), &c, &cfg, n, (const uint8_t*)qseq.data(), qoff.data(), score.data(), pairs.data(),
+                                           pair_off.data(), cap, flags.data(), stats, counters.empty() ? nullptr : counters.data(), device_);
+        } else {
+            const poa_costs_t c{config_.costs.mismatch(), config_.costs.gap_open(), config_.costs.gap_extend(), 0};
+            rc = poa_align_batch_ex(g.device_graph(), &c, &cfg, n, (const uint8_t*)qseq.data(), qoff.data(), score.data(),
+                                    pairs.data(), pair_off.data(), cap, flags.data(), stats, device_);
+        }
         if (rc != POA_OK) throw PoastaError(std::string("poa_align_batch: ") + poa_last_error());
         std::vector<AstarResult> out(n);
         for (uint32_t i = 0; i < n; ++i) {
             out[i].score = score[i]; out[i].flags = flags[i];
+            if (!counters.empty()) { out[i].num_queued = counters[4 * (size_t)i]; out[i].num_visited = counters[4 * (size_t)i + 1]; out[i].num_pruned = counters[4 * (size_t)i + 2]; }
             for (uint64_t k = pair_off[i]; k < pair_off[i + 1]; ++k) {
                 AlignedPair ap;
                 if (pairs[k].rpos != POA_NONE) ap.rpos = pairs[k].rpos;

@@ -6,7 +6,7 @@
 // does not shard — DESIGN.md §7); `--mode hybrid` (default) returns the reference's own tie-breaks, which the graph
 // update consumes verbatim.
 //
-//   poasta_align_amd align [-n MISMATCH] [-g OPEN] [-e EXTEND] [-I graph.msa.fa] [-o OUT] [--mode dense|exact|hybrid]
+//   poasta_align_amd align [-n MISMATCH] [-g OPEN[,OPEN2]] [-e EXTEND[,EXTEND2]] [-H mingap|dijkstra] [-m global|semi-global|ends-free] [-I graph.msa.fa] [-o OUT] [--mode dense|exact|hybrid]
 //                          [--device N] [--alignments FILE] READS.fa
 //   poasta_align_amd replay ALIGNMENTS.txt          (no GPU: graph update + export from recorded alignments)
 #include <chrono>
@@ -79,19 +79,22 @@ int main(int argc, char** argv) {
     try {
         if (argc >= 3 && std::strcmp(argv[1], "replay") == 0) return replay(argv[2]);
         if (argc < 3 || std::strcmp(argv[1], "align") != 0) {
-            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6] [-e 2] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--device 0] [--alignments file] [--timing file.tsv] reads.fa\n"
+            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6 | 6,24] [-e 2 | 2,1] [-H mingap|dijkstra] [-m global|semi-global|ends-free] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--device 0] [--alignments file] [--timing file.tsv] reads.fa\n"
                                  "       poasta_align_amd replay alignments.txt\n");
             return 2;
         }
-        int mismatch = 4, open = 6, extend = 2, device = 0;
+        int mismatch = 4, device = 0;
+        std::string open_s = "6", extend_s = "2", heuristic = "mingap", span = "global";
         std::string out_path, msa_path, aln_path, timing_path, mode = "hybrid";
         std::vector<std::string> pos;
         for (int i = 2; i < argc; ++i) {
             const std::string a = argv[i];
             auto need = [&](const char* what) { if (i + 1 >= argc) throw PoastaError(std::string("missing value for ") + what); return std::string(argv[++i]); };
             if (a == "-n") mismatch = std::stoi(need("-n"));
-            else if (a == "-g") open = std::stoi(need("-g"));
-            else if (a == "-e") extend = std::stoi(need("-e"));
+            else if (a == "-g") open_s = need("-g");            // "6" or, two-piece model, "6,24" (poasta.rs:122-131)
+            else if (a == "-e") extend_s = need("-e");
+            else if (a == "-H" || a == "--heuristic") heuristic = need("-H");
+            else if (a == "-m" || a == "--alignment-span") span = need("-m");
             else if (a == "-o") out_path = need("-o");
             else if (a == "-I" || a == "--graph") msa_path = need("-I");
             else if (a == "--mode") mode = need("--mode");
@@ -106,9 +109,39 @@ int main(int argc, char** argv) {
         bool warned_dense = false;
         graphs::POAGraph graph;
         if (!msa_path.empty()) graph = io::load_graph_from_fasta_msa(read_fasta(msa_path));
-        // GapAffine::new(mismatch, extend, open): the reference's argument order (gap_affine.rs:27)
-        aligner::PoastaAligner<aligner::AffineMinGapCost> al(aligner::AffineMinGapCost(aligner::GapAffine((uint8_t)mismatch, (uint8_t)extend, (uint8_t)open)),
-                                                             aligner::AlignmentType::Global, device, m);
+        // poasta.rs:275-445: heuristic, span and cost model select the aligner
+        auto values = [](const std::string& s) {   // parse_gap_penalties: comma-separated u8 values
+            std::vector<int> v; size_t at = 0;
+            while (at <= s.size()) { const size_t c = s.find(',', at); v.push_back(std::stoi(s.substr(at, c == std::string::npos ? c : c - at))); if (c == std::string::npos) break; at = c + 1; }
+            return v;
+        };
+        const std::vector<int> go = values(open_s), ge = values(extend_s);
+        bool two_piece = go.size() == 2 && ge.size() == 2;
+        if (!two_piece && (go.size() != 1 || ge.size() != 1))
+            throw PoastaError("Standard affine mode requires exactly 1 value for both gap-open and gap-extend (e.g., -g 6 -e 2)");
+        if (two_piece && ge[0] <= ge[1]) {   // poasta.rs:339-342
+            std::fprintf(stderr, "Warning: gap_extend1 (%d) should be greater than gap_extend2 (%d) for two-piece model\nUsing standard affine gap model instead.\n", ge[0], ge[1]);
+            two_piece = false;
+        }
+        if (heuristic != "mingap" && heuristic != "dijkstra")
+            throw PoastaError(heuristic == "path" ? "heuristic 'path' (PathAware) is not part of this engine: use mingap or dijkstra"
+                                                  : "Invalid heuristic type. Valid options are: dijkstra, mingap, path");
+        aligner::AlignmentType aln_type = aligner::AlignmentType::Global;
+        if (span == "semi-global" || span == "ends-free") aln_type = aligner::AlignmentType::EndsFree();   // both all-Unbounded: poasta.rs:287-300
+        else if (span != "global") throw PoastaError("alignment span: global, semi-global or ends-free");
+        const bool dij = heuristic == "dijkstra";
+        // GapAffine::new(mismatch, extend, open) / GapAffine2Piece::new(mismatch, extend1, open1, extend2, open2): the reference's argument orders
+        const aligner::GapAffine c1((uint8_t)mismatch, (uint8_t)ge[0], (uint8_t)go[0]);
+        const aligner::GapAffine2Piece c2 = two_piece ? aligner::GapAffine2Piece((uint8_t)mismatch, (uint8_t)ge[0], (uint8_t)go[0], (uint8_t)ge[1], (uint8_t)go[1])
+                                                      : aligner::GapAffine2Piece((uint8_t)mismatch, (uint8_t)ge[0], (uint8_t)go[0], (uint8_t)ge[0], (uint8_t)go[0]);
+        const aligner::PoastaAligner<aligner::AffineMinGapCost> al_m(aligner::AffineMinGapCost(c1), aln_type, device, m);
+        const aligner::PoastaAligner<aligner::AffineDijkstra> al_d(aligner::AffineDijkstra(c1), aln_type, device, m);
+        const aligner::PoastaAligner<aligner::Affine2PieceMinGapCost> al2_m(aligner::Affine2PieceMinGapCost(c2), aln_type, device, m);
+        const aligner::PoastaAligner<aligner::Affine2PieceDijkstra> al2_d(aligner::Affine2PieceDijkstra(c2), aln_type, device, m);
+        auto align_one = [&](const graphs::POAGraph& gr, const std::string& seq, poa_stats_t* st) {
+            if (two_piece) return dij ? al2_d.align_batch(gr, {seq}, true, st).at(0) : al2_m.align_batch(gr, {seq}, true, st).at(0);
+            return dij ? al_d.align_batch(gr, {seq}, true, st).at(0) : al_m.align_batch(gr, {seq}, true, st).at(0);
+        };
         std::ofstream alog, tlog;
         if (!timing_path.empty()) { tlog.open(timing_path); tlog << "read\tlen\tgraph_nodes\tus_graph_refresh\tus_align_call\tus_h2d\tus_dense_kernels\tus_replay\tus_d2h\tus_graph_update\n"; }
         if (!aln_path.empty()) alog.open(aln_path);
@@ -126,7 +159,7 @@ int main(int argc, char** argv) {
                 (void)graph.device_graph();                                                   // poa_graph_update: re-flatten in place
                 const auto t1 = clk::now();
                 poa_stats_t st{};
-                const aligner::AstarResult r = al.align_batch(graph, {rec.second}, true, &st).at(0);   // poasta.rs:214
+                const aligner::AstarResult r = align_one(graph, rec.second, &st);   // poasta.rs:214
                 const auto t2 = clk::now();
                 std::fprintf(stderr, "Aligned '%s' (len=%zu) - Score: %u, Alignment length: %zu, flags 0x%x\n", rec.first.c_str(),
                              rec.second.size(), r.score, r.alignment.size(), r.flags);

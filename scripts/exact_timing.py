@@ -13,9 +13,10 @@ ap.add_argument("--mode", default="exact")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--scale", type=float, default=1.0, help="config 2 scaled down: backbone, bubbles and query length x scale")
+ap.add_argument("--length", type=int, default=1000, help="0: the reads without their random padding to 1 kbp (~925 bases)")
 args = ap.parse_args()
 if args.scale == 1.0:
-    g, (qseq, qoff) = W.config2(n_queries=args.queries)
+    g, (qseq, qoff) = W.config2(n_queries=args.queries, length=args.length)
 else:
     k = args.scale
     g, (qseq, qoff) = W.scaled_linearish(int(900 * k), int(50 * k), int(25 * k), args.queries, int(1000 * k))
@@ -31,7 +32,7 @@ for _ in range(args.reps):
 dt, st = best
 res = rb.fetch()
 cells = g.n * float((np.diff(qoff) + 1).sum())
-out = dict(mode=args.mode, queries=args.queries, wall_s=round(dt, 4), gcells_per_s=round(cells / dt / 1e9, 2), ms_forward=st["ms_forward"],
+out = dict(mode=args.mode, queries=args.queries, n_chunks=st.get("n_chunks"), wall_s=round(dt, 4), gcells_per_s=round(cells / dt / 1e9, 2), ms_forward=st["ms_forward"],
            ms_traceback=st["ms_traceback"], ms_exact=st["ms_exact"], n_exact=res.stats["n_exact"], flagged=int((res.flags != 0).sum()),
            overflow=int(((res.flags & 0x40) != 0).sum()), impl=os.environ.get("POA_EXACT_IMPL", "wave"))
 try:

@@ -239,3 +239,40 @@ def test_gpu_sequential_poa_build_equals_oracle_msa(driver, oracle, tmp_path):
     truth = [l for l in open(os.path.join(GOLD, "small_test.truth.fa")).read().splitlines() if not l.startswith(">")]
     rows = [l for l in out.splitlines() if not l.startswith(">")]
     assert rows[:2] == truth[:2] and rows[2] == truth[2][1:]   # the reference-held MSA, up to the export's leading-gap quirk
+
+
+@pytest.mark.gpu
+def test_gpu_sequential_poa_cli_options_two_piece_heuristic_span(driver, oracle, tmp_path):
+    """The CLI's other aligner selections (src/bin/poasta.rs:275-445) on the engine: `-g 6,24 -e 2,1` (Affine2PieceMinGapCost:
+    every read through the replay of the five-state search), `-H dijkstra`, `-m ends-free`, and the fallback to the one-piece
+    model when extend1 <= extend2 — MSAs byte-identical to the oracle's sequential builds under the same configuration."""
+    fa = os.path.join(GOLD, "test2_from_abpoa.fa")
+    recs = oracle.read_fasta(fa)
+    run = lambda *opts: subprocess.check_output([ALIGN_DRIVER, "align", *opts, fa], stderr=subprocess.DEVNULL).decode()
+    with oracle.two_piece(24, 1):
+        g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2))
+    assert run("-g", "6,24", "-e", "2,1") == g.to_fasta()
+    with oracle.two_piece(24, 1):
+        g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2), heuristic=oracle.H_DIJKSTRA)
+    assert run("-g", "6,24", "-e", "2,1", "-H", "dijkstra") == g.to_fasta()
+    g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2), heuristic=oracle.H_DIJKSTRA)
+    assert run("-H", "dijkstra") == g.to_fasta()
+    g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2))
+    assert run("-g", "6,24", "-e", "2,2") == g.to_fasta()          # poasta.rs:339-342: standard affine with the first values
+    ef = oracle.ends_free(oracle.UNBOUNDED, oracle.UNBOUNDED, oracle.UNBOUNDED, oracle.UNBOUNDED)
+    for two in (False, True):
+        opts = ("-m", "ends-free") + (("-g", "6,24", "-e", "2,1") if two else ())
+        try:
+            with oracle.alignment_type(ef):
+                if two:
+                    with oracle.two_piece(24, 1):
+                        g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2))
+                else:
+                    g, _ = oracle.sequential_poa(recs, oracle.Costs(4, 6, 2))
+        except (oracle.RefPanic, RuntimeError):
+            # the reference's build stops here (a panic, or add_alignment_with_weights returns InvalidAlignment for what an
+            # all-Unbounded search hands it, poa.rs:171-180): so does the twin
+            assert subprocess.run([ALIGN_DRIVER, "align", *opts, fa], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL).returncode != 0
+            continue
+        assert run(*opts) == g.to_fasta(), opts
+    assert subprocess.run([ALIGN_DRIVER, "align", "-H", "path", fa], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL).returncode == 1
