@@ -17,7 +17,7 @@ ap.add_argument("--seconds", type=float, default=240.0)
 ap.add_argument("--verbose", action="store_true")
 args = ap.parse_args()
 t0 = time.time()
-n_dense = n_exact = n_cases = 0
+n_dense = n_exact = n_exact2 = n_cases = 0
 for seed in range(args.first, args.first + args.seeds):
     if time.time() - t0 > args.seconds:
         break
@@ -138,7 +138,42 @@ for seed in range(args.first, args.first + args.seeds):
                                       gpu=[int(rx.score[i]), int(rx.flags[i])], oracle=[int(A["status"][i]), int(A["score"][i])])))
                 sys.exit(1)
             n_exact += 1
+    if g.n * max(len(q) for q in qs) < 150000 and kind != 5:
+        # two-piece model: the replay of the five-state search (poa_align_batch_2piece_ex), random second piece
+        e2, o2 = int(rng.integers(0, e + 1)), int(rng.integers(0, 30))
+        heur, prune = (O.H_MINGAP, True) if seed % 2 else (O.H_DIJKSTRA, seed % 4 == 0)
+        cfg2 = E.Affine2PieceMinGapCost if heur == O.H_MINGAP else E.Affine2PieceDijkstra
+        if span is None:
+            at, ospec = E.AlignmentType.Global, None
+        else:
+            B = E.Bound
+            conv = lambda b: B.Unbounded if b[0] == 0 else (B.Included(b[1]) if b[0] == 1 else B.Excluded(b[1]))
+            at = E.AlignmentType.EndsFree(qry_free_end=conv(span["qry_free_end"]), graph_free_begin=conv(span["graph_free_begin"]),
+                                          graph_free_end=conv(span["graph_free_end"]))
+            ob = lambda b: b if b[0] else 0
+            ospec = O.ends_free(0, ob(span["qry_free_end"]), ob(span["graph_free_begin"]), ob(span["graph_free_end"]))
+        r2 = E.PoastaAligner(cfg2(E.GapAffine2Piece(m, e, o, e2, o2)), aln_type=at, mode="exact", queue_entries_per_cell=16.0).align_batch(
+            g, qseq=qseq, qoff=qoff, pruning=prune)
+        with O.two_piece(o2, e2):
+            if ospec is None:
+                A2 = og.astar_batch(qseq, qoff, oc, heur, prune, threads=8, want_counters=True)
+            else:
+                with O.alignment_type(ospec):
+                    A2 = og.astar_batch(qseq, qoff, oc, heur, prune, threads=8, want_counters=True)
+        for i in range(len(qs)):
+            if int(r2.flags[i]) & 0x40:
+                continue
+            if A2["status"][i] != 0:
+                ok = bool(int(r2.flags[i]) & (4 | 0x10))
+            else:
+                ok = (int(r2.flags[i]) & ~0x10 == 0 and int(r2.score[i]) == int(A2["score"][i]) and r2.raw_alignment(i) == O.batch_alignment(A2, i)
+                      and r2.search_counters[i, :3].tolist() == [int(x) for x in A2["counters"][i]])
+            if not ok:
+                print(json.dumps(dict(fail="two-piece exact", seed=seed, kind=kind, query=i, costs=costs + (o2, e2), heur=heur, prune=prune,
+                                      gpu=[int(r2.score[i]), int(r2.flags[i])], oracle=[int(A2["status"][i]), int(A2["score"][i])])))
+                sys.exit(1)
+            n_exact2 += 1
     n_cases += 1
     if n_cases % 100 == 0:  # keeps a long run visibly alive
         print(json.dumps(dict(progress=n_cases, seconds=round(time.time() - t0, 1))), flush=True)
-print(json.dumps(dict(ok=True, graphs=n_cases, dense_queries=n_dense, exact_queries=n_exact, seconds=round(time.time() - t0, 1))))
+print(json.dumps(dict(ok=True, graphs=n_cases, dense_queries=n_dense, exact_queries=n_exact, two_piece_exact_queries=n_exact2, seconds=round(time.time() - t0, 1))))
