@@ -964,8 +964,10 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 if (const int* cv = T.ptr(POA_TUNE_WS_CHUNK_CAP)) { const int v = (*cv); if (v >= 1 && (uint32_t)v < wp.chunk_cap) wp.chunk_cap = (uint32_t)v; }
                 wp.win = win;
                 wp.counters = b->d_ex_counters.p;
-                wp.max_lanes = 16;   // entries tested per step: runs of stale / pruned entries are short (1.85 pops per step)
+                wp.max_lanes = 32;   // entries tested per step at most: runs of stale / pruned entries are short (1.85 pops per step)
                 if (const int* lv = T.ptr(POA_TUNE_WS_LANES)) { const int v = (*lv); if (v >= 1 && v <= 63) wp.max_lanes = (uint32_t)v; }
+                wp.adapt_lanes = 4;   // after an expansion the top of the stack is fresh: few entries tested; a run that used up its lanes widens
+                if (const int* av = T.ptr(POA_TUNE_WS_ADAPT)) { const int v = (*av); if (v >= 0 && v <= 63) wp.adapt_lanes = (uint32_t)v; }
                 wp.prof = nullptr;
                 if (T.ptr(POA_TUNE_WS_PROF)) wp.prof = b->d_ex_prof.p;  // per-phase cycle counts of the wave search (diagnostics)
                 // Lanes per query.  One query per wave (64) with persistent scheduling is the default.  Several queries per wave

@@ -36,6 +36,7 @@ struct WSearchParams {
     uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
     uint32_t waves_per_block;
     uint32_t max_lanes;       // entries tested per step (<= 63)
+    uint32_t adapt_lanes;     // 0: always max_lanes; else the step after an expansion tests this many, and a run that used up its lanes four times as many
     uint32_t group;           // lanes per query: 64 (one query per wave), 32, 16 or 8
     // persistent scheduling (group == 64): the launch holds as many waves as are resident at once; each takes the next
     // query of `order` (longest expected search first) from `work_counter` until none is left, so that no wave waits for
@@ -286,10 +287,11 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
     const bool prof = P.prof != nullptr;
 #define WS_TICK(k) do { if (prof) { const unsigned long long now_ = clock64(); pc[k] += now_ - t_last; t_last = now_; } } while (0)
     unsigned long long t_last = prof ? clock64() : 0;
+    uint32_t lanes_now = P.adapt_lanes ? (P.adapt_lanes < P.max_lanes ? P.adapt_lanes : P.max_lanes) : P.max_lanes;
     while (!found && !S.err) {
         uint32_t st; BqDesc d;
         if (!S.bq_current(st, d)) { S.err = EX_PANIC; break; }  // "Could not align sequence!" (astar.rs:142-144)
-        const uint32_t nb = d.n_top < P.max_lanes ? d.n_top : P.max_lanes;  // <= 63 entries in the top chunk: lane i takes the i-th from the top
+        const uint32_t nb = d.n_top < lanes_now ? d.n_top : lanes_now;  // <= 63 entries in the top chunk: lane i takes the i-th from the top
         const ExU4* ch = W.bq_chunks + (uint64_t)BQ_CHUNK * d.top;
         const bool act = lane < nb;
         const ExU4 e = ch[act ? d.n_top - lane : 0];  // the idle lanes read slot 0: {previous chunk}
@@ -303,6 +305,9 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
         const uint64_t stop = __ballot(act && (sk == 0 || sk == 3 || S.err != 0));
         WS_TICK(1);
         const uint32_t n = stop ? (uint32_t)__builtin_ctzll(stop) : nb;
+        // the next step: after an expansion what lies on top was just pushed (rarely stale): few lanes — each tested entry costs
+        // loads and its own branch of the test; a run of stale / pruned entries that used up its lanes goes on wider
+        if (P.adapt_lanes) { lanes_now = n < nb ? P.adapt_lanes : 4 * lanes_now; if (lanes_now > P.max_lanes) lanes_now = P.max_lanes; }
         if (lane < n && sk == 2) S.num_pruned += 1;   // per-lane tallies, summed at the end
         if (lane > n) S.err = 0;                      // tests beyond the run are discarded with whatever they hit
         const uint32_t prev = ws_bcast(e.x, 63);      // lane 63 is never active (nb <= 63)

@@ -262,8 +262,9 @@ def test_gpu_two_piece_exact_replay_equals_the_search(engine, oracle):
 @pytest.mark.gpu
 def test_gpu_two_piece_exact_config2_sample(engine, oracle):
     """configs[1] shape under `poasta align -g 6,24 -e 2,1` (Affine2PieceMinGapCost, pruning on, Global): every alignment
-    of a sample bit-identical to the oracle's search, several workspace chunks."""
-    g, (qseq, qoff) = W.config2(n_queries=24)
+    of a 256-query sample bit-identical to the oracle's search (scores, alignments, search counters)."""
+    NQ = 256
+    g, (qseq, qoff) = W.config2(n_queries=NQ)
     al = engine.PoastaAligner(engine.Affine2PieceMinGapCost(engine.GapAffine2Piece(4, 2, 6, 1, 24)), mode="exact")
     res = al.align_batch(g, qseq=qseq, qoff=qoff)
     og = oracle.OracleGraph.from_csr(g.as_dict())
@@ -272,5 +273,17 @@ def test_gpu_two_piece_exact_config2_sample(engine, oracle):
     assert not A["status"].any() and not res.flags.any()
     assert np.array_equal(res.score, A["score"])
     assert np.array_equal(res.search_counters[:, :3], A["counters"].astype(np.uint32))
-    for i in range(24):
+    for i in range(NQ):
         assert res.raw_alignment(i) == oracle.batch_alignment(A, i)
+    # the cases where the literal search leaves the optimum (test_score_relations_of_the_reference_tests): ACGTACGT x
+    # ACGTTTTTTTACGT under (1, 3, 12, 1, 6): Dijkstra without pruning 20 = the optimum, with pruning 23, min-gap without pruning 38
+    from poasta_amd.graph import GraphBuilder
+    b = GraphBuilder()
+    b.add_path(np.frombuffer(b"ACGTACGT", np.uint8))
+    g8 = b.finish()
+    c = engine.GapAffine2Piece(1, 3, 12, 1, 6)
+    q = [np.frombuffer(b"ACGTTTTTTTACGT", np.uint8)]
+    ex = lambda cfg, prune: int(engine.PoastaAligner(cfg(c), mode="exact").align_batch(g8, q, pruning=prune).score[0])
+    assert ex(engine.Affine2PieceDijkstra, False) == 20 == int(engine.PoastaAligner(engine.Affine2PieceDijkstra(c)).align_batch(g8, q).score[0])
+    assert ex(engine.Affine2PieceDijkstra, True) == 23
+    assert ex(engine.Affine2PieceMinGapCost, False) == 38
