@@ -127,6 +127,7 @@ enum {
     POA_TUNE_PS_LEAN,         /* 0: flat kernel with the generic code in log mode */
     POA_TUNE_TIMING,          /* poa_align_batch: host-side timing printed to stderr */
     POA_TUNE_WS_ADAPT,        /* wave replay: entries tested in the step after an expansion (0: always WS_LANES) */
+    POA_TUNE_WS_REC,          /* 0: the wave replay's one-round-trip path reads the graph arrays instead of the per-row records */
     POA_TUNE_COUNT = 32
 };
 

@@ -47,7 +47,7 @@ class PoaConfig(C.Structure):
 # sweep set POA_<NAME> and this binding copies them into the config of every call (tune_from_env).
 TUNE_KEYS = ("PLANES", "COMPACT", "PACKED", "RELATIVE", "PX", "MF", "MW", "PXMW", "FWD_QUADS", "FUSE_TB", "TB_GROUP", "TB_DEPTH",
              "EXACT_IMPL", "EXACT_LANES", "EXACT_LDS", "WS_LANES", "WS_GROUP", "WS_WAVES", "WS_RING_GLOBAL", "WS_STATIC",
-             "WS_CHUNK_CAP", "WS_PROF", "PS_LANES", "PS_LEAN", "TIMING", "WS_ADAPT")
+             "WS_CHUNK_CAP", "WS_PROF", "PS_LANES", "PS_LEAN", "TIMING", "WS_ADAPT", "WS_REC")
 EXACT_IMPLS = {"lane": 1, "wave": 2, "flat": 3}
 
 

@@ -546,6 +546,8 @@ static int prepare_exact(poa_batch* b, const poa_costs_t* costs, const poa_confi
     if (n_prio64 > (1ull << 26)) return fail(POA_ERR_UNSUPPORTED, "exact replay: priority range too large for this graph / query size");
     if (3ull * n * (((uint64_t)b->max_len + 64) & ~63ull) >= (1ull << 32))
         return fail(POA_ERR_UNSUPPORTED, "exact replay: the visited table of one query exceeds 2^32 cells");
+    if ((uint64_t)fg.n_exit * ((b->max_len + 64) / 64) >= (1ull << 32))   // (the reached sets are indexed in 32-bit arithmetic)
+        return fail(POA_ERR_UNSUPPORTED, "exact replay: reached sets of one query exceed 2^32 words");
     const float f = (cfg && cfg->queue_entries_per_cell > 0.f) ? cfg->queue_entries_per_cell : 0.25f;
     const uint64_t pool64 = std::max<uint64_t>(256, (uint64_t)(f * (double)n * (double)(b->max_len + 1)));
     if (pool64 > 0xFFFFFFF0ull) return fail(POA_ERR_UNSUPPORTED, "exact replay: queue pool too large");
@@ -981,6 +983,8 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 if (const int* wv = T.ptr(POA_TUNE_WS_WAVES)) { const int v = (*wv); if (v >= 1 && v <= 16) wpb = (uint32_t)v; }
                 const uint64_t lds_budget = std::min<uint64_t>((uint64_t)lds_cap, 80u * 1024u);
                 bool ring_lds = false, stage = false;
+                // per-row records of the one-round-trip path (one query per wave: a block of 16 waves has the CU to itself)
+                uint32_t rec_lds = 0;
                 for (;;) {
                     const uint64_t rb = (uint64_t)wpb * (64 / group) * win * 12;
                     ring_lds = rb <= lds_budget && !T.ptr(POA_TUNE_WS_RING_GLOBAL);
@@ -991,12 +995,17 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                     if (wpb > 2 && !T.ptr(POA_TUNE_WS_WAVES)) wpb /= 2; else { group *= 2; if (!T.ptr(POA_TUNE_WS_WAVES)) wpb = 16; }
                 }
                 const uint64_t ring_bytes = ring_lds ? (uint64_t)wpb * (64 / group) * win * 12 : 0;
+                if (group == 64 && stage && ring_lds && !fg.row_rec.empty() && !(T.ptr(POA_TUNE_WS_REC) && *T.ptr(POA_TUNE_WS_REC) == 0)) {
+                    const uint64_t rb = (fg.row_rec.size() * sizeof(FlatGraph::RowRec) + 15) & ~15ull;
+                    if (graph_lds + rb + ring_bytes <= std::min<uint64_t>((uint64_t)lds_cap, 150u * 1024u)) rec_lds = (uint32_t)rb;
+                }
+                wp.rec_lds = rec_lds;
                 wp.graph_lds = stage ? graph_lds : 0;
                 wp.waves_per_block = wpb;
                 wp.group = group;
                 wp.ring_global = nullptr;
                 if (!ring_lds) wp.ring_global = b->d_ex_head.p;  // [slots * 3 * ex_n_prio] holds slots * 3 * win
-                const uint32_t lds_bytes = wp.graph_lds + (uint32_t)ring_bytes;
+                const uint32_t lds_bytes = wp.graph_lds + wp.rec_lds + (uint32_t)ring_bytes;
                 const void* kfn = group == 64 ? reinterpret_cast<const void*>(poa_wsearch_kernel) : reinterpret_cast<const void*>(poa_wsearch_groups_kernel);
                 if (lds_bytes > 48u * 1024u)
                     HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -224,6 +224,10 @@ public:
     SpecLane sl;
     static constexpr bool TP = (AS & EX_AS_TWO_PIECE) != 0;
     static constexpr uint32_t NST = TP ? 5u : 3u;   // states (planes of the table, stacks per priority)
+    // the one-round-trip path of the wave kernels reads the per-row records when the launch staged them (EX_AS_REC_LDS | EX_AS_NO_SPEC)
+    POA_HD bool use_rec() const {
+        if constexpr ((AS & EX_AS_NO_SPEC) != 0 && (AS & EX_AS_REC_LDS) != 0) return G.rec != nullptr; else return false;
+    }
     POA_HD bool in_spec() const { if constexpr ((AS & EX_AS_NO_SPEC) != 0) return false; else return spec; }
 #if defined(POA_PS_PROF_FINE)
     unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = 0;
@@ -901,6 +905,7 @@ public:
     struct Probe {
         uint32_t on;          // 0: nothing to test (no such bubble, pruning off, t beyond the query)
         uint32_t ex, t, wi;
+        uint32_t x, mde;      // index of the exit row among the exit rows; max(dist_min[exit] - 1, 0)
         uint64_t w1, sum;     // the word of the reached set that holds t; the summary word (which words are non-empty)
         uint32_t ta, tb, tc;  // Match score of the exit row at t - 1, t, t + 1
     };
@@ -920,7 +925,21 @@ public:
         P.on = ((C.prune || !pop_level) && ex[0] != EX_NIL && P.t <= L) ? 1u : 0u;   // reached.rs:63-65: tmax > len -> can improve
         Q.ex = ex[1]; Q.t = j + dist[1]; Q.wi = Q.t >> 6;
         Q.on = ((C.prune || !pop_level) && ex[1] != EX_NIL && Q.t <= L) ? 1u : 0u;
+        P.x = P.mde = Q.x = Q.mde = 0;
+        if (P.on) { P.x = gld(&G.exit_idx[P.ex]); const uint32_t m = gld(&G.dist_min[P.ex]); P.mde = m ? m - 1 : 0; }
+        if (Q.on) { Q.x = gld(&G.exit_idx[Q.ex]); const uint32_t m = gld(&G.dist_min[Q.ex]); Q.mde = m ? m - 1 : 0; }
         return !((P.on && P.t + 1 >= W.pitch) || (Q.on && Q.t + 1 >= W.pitch));   // (the loads below read t + 1)
+    }
+    // the same from the row's record (FlatGraph::RowRec: one 32-byte load instead of the walk through the bubble map, the exit
+    // index and the exit's distance); false also where the record does not hold the whole truth (the generic code decides)
+    POA_HD bool probe_setup_rec(const FlatGraph::RowRec& rr, uint32_t j, Probe& P, Probe& Q, bool pop_level) const {
+        if (!(rr.flags & FlatGraph::RR_PROBE_OK) || rr.d0min != rr.d0max || rr.d1min != rr.d1max) return false;
+        const bool en = C.prune || !pop_level;
+        P.ex = rr.e0 == 0xFFFFu ? EX_NIL : (uint32_t)rr.e0; P.t = j + rr.d0min; P.wi = P.t >> 6; P.x = rr.x0; P.mde = rr.mde0;
+        P.on = (en && rr.e0 != 0xFFFFu && P.t <= L) ? 1u : 0u;
+        Q.ex = rr.e1 == 0xFFFFu ? EX_NIL : (uint32_t)rr.e1; Q.t = j + rr.d1min; Q.wi = Q.t >> 6; Q.x = rr.x1; Q.mde = rr.mde1;
+        Q.on = (en && rr.e1 != 0xFFFFu && Q.t <= L) ? 1u : 0u;
+        return !((P.on && P.t + 1 >= W.pitch) || (Q.on && Q.t + 1 >= W.pitch));
     }
     // both tests: 0 can improve, 2 pruned, 3 undecided (the generic code decides)
     POA_HD uint32_t probe_decide2(const Probe& P, const Probe& Q, uint32_t g, uint32_t st) {
@@ -931,7 +950,7 @@ public:
     POA_HD void probe_load(Probe& P) const {
         P.w1 = P.sum = 0; P.ta = P.tb = P.tc = EX_INF;
         if (!P.on) return;
-        const uint32_t x = gld(&G.exit_idx[P.ex]);
+        const uint32_t x = P.x;
         P.sum = rsw(x, 0);
         P.w1 = rword(x, P.wi);
         const uint32_t ia = cix(P.ex, P.t ? P.t - 1 : 0, EX_ST_M), ib = cix(P.ex, P.t, EX_ST_M), ic = cix(P.ex, P.t + 1, EX_ST_M);
@@ -944,7 +963,7 @@ public:
     // reached.rs:38-255 specialised to tmin == tmax.
     POA_HD uint32_t probe_decide(const Probe& P, uint32_t g, uint32_t st) {
         if (!P.on) return 0;                        // no bubble to test
-        if (P.sum == 0) { if (in_spec()) note_marks(gld(&G.exit_idx[P.ex]), 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
+        if (P.sum == 0) { if (in_spec()) note_marks(P.x, 0, 0xFFFFFFFFu); return 0; }   // nothing reached at the exit yet (reached.rs:52-54)
         const uint32_t t = P.t, wi = P.wi, ex = P.ex;
         uint32_t prev = EX_NIL, nxt = EX_NIL;
         const bool at_t = (P.w1 >> (t & 63)) & 1;
@@ -963,7 +982,7 @@ public:
         // what the decision read of the exit row: the marks between the two neighbours and the scores at them (reached at t:
         // the neighbour above is not looked at, reached.rs:139)
         if (in_spec()) {
-            note_marks(gld(&G.exit_idx[ex]), prev == EX_NIL ? 0u : prev, at_t ? t : nxt);
+            note_marks(P.x, prev == EX_NIL ? 0u : prev, at_t ? t : nxt);
             if (prev != EX_NIL && prev < W.pitch) note_cell(cix(ex, prev, EX_ST_M));
             if (at_t) note_cell(cix(ex, t, EX_ST_M));
             else if (nxt != EX_NIL && nxt < W.pitch) note_cell(cix(ex, nxt, EX_ST_M));
@@ -978,7 +997,7 @@ public:
         const uint32_t tb = P.tb;
         // a reached cell holds a score; if one does not, the generic code reports what the reference would (a panic)
         if ((prev != EX_NIL && ls == EX_INF) || (nxt != EX_NIL && rs == EX_INF) || (at_t && tb == EX_INF)) return 3;
-        uint32_t mde = gld(&G.dist_min[ex]); mde = mde ? mde - 1 : 0;
+        const uint32_t mde = P.mde;
         bool improve;
         if (at_t) {
             // the loop body of reached.rs:67-141 runs once with next == t; afterwards prev == t (reached.rs:139, :177-186)
@@ -1016,13 +1035,31 @@ public:
     POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
         F.kind = 0;
         if constexpr (TP) return 3;   // (two-piece model: the generic code)
+        uint32_t c, c1, kind = 1;
+        Probe P, Q;
+        bool probes;
+        if (use_rec()) {
+            // everything the test needs to know of the row in one record: successors, their symbols, the bubbles ahead
+            const FlatGraph::RowRec rr = lrec(v);
+            const uint32_t fl = rr.flags;
+            if (C.ends_free || (fl & FlatGraph::RR_END) || rr.c0 == 0xFFFFu || (st != EX_ST_I && !(fl & FlatGraph::RR_SUCC_OK)) || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) return 3;
+            c = rr.c0;
+            c1 = ((fl & FlatGraph::RR_HAS_C1) && st != EX_ST_I) ? (uint32_t)rr.c1 : EX_NIL;
+            if (st == EX_ST_M) {
+                if (j >= L) return 3;
+                if (j == 0 && L != 0 && rr.sym == seq[0]) return 3;   // the offset-0 special case, dfa.rs:146-167
+                const uint8_t qc = seq[j];
+                if (rr.sym0 == qc) kind = 2;
+                if (c1 != EX_NIL && rr.sym1 == qc) return 3;
+            }
+            probes = probe_setup_rec(rr, j, P, Q, true);
+        } else {
         const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
         const uint32_t ns = s1 - s0;
         // (an Insertion state never looks at the successors — expand_all, gap_affine.rs:307-341)
         if (C.ends_free || ((ns == 0 || ns > 2) && (st != EX_ST_I || ns == 0)) || v == G.end_row || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) { EXD(ns != 1 ? 1 : 2, st); return 3; }
-        const uint32_t c = gld(&G.succ[s0]);
-        const uint32_t c1 = (ns == 2 && st != EX_ST_I) ? gld(&G.succ[s0 + 1]) : EX_NIL;
-        uint32_t kind = 1;
+        c = gld(&G.succ[s0]);
+        c1 = (ns == 2 && st != EX_ST_I) ? gld(&G.succ[s0 + 1]) : EX_NIL;
         if (st != EX_ST_I && (c == G.end_row || c1 == G.end_row)) { EXD(4, st); return 3; }
         if (st == EX_ST_M) {
             // a Match state goes through the greedy extension
@@ -1032,8 +1069,8 @@ public:
             if (gld(&G.sym[c]) == qc) kind = 2;
             if (c1 != EX_NIL && gld(&G.sym[c1]) == qc) { EXD(1, st); return 3; }   // (a second branch to extend: the generic code keeps the stack)
         }
-        Probe P, Q;
-        const bool probes = probe_setup(v, j, P, Q, true);
+        probes = probe_setup(v, j, P, Q, true);
+        }
         if constexpr ((AS & EX_AS_NO_SPEC) != 0) { if (!probes) { EXD(3, st); return 3; } }   // (wave kernels: the generic code takes it, nothing loaded twice)
         // ---- every load of the step, before any use ----
         const uint32_t i_own = cix(v, j, st);
@@ -1106,10 +1143,19 @@ public:
             if (!(g < tm)) break;                          // already there with this score or better: not extended (dfa.rs:242)
             wr(cc, nj, EX_ST_M, g);
             // what the tip needs next: its own successor, its bubble test, and what a mismatch there relaxes
-            const uint32_t s0 = gld(&G.succ_off[cc]), s1 = gld(&G.succ_off[cc + 1]);
-            const uint32_t nc = s1 - s0 == 1 ? gld(&G.succ[s0]) : EX_NIL;
+            uint32_t nc, nsym = 0;
             Probe P, Q;
-            const bool shaped = probe_setup(cc, nj, P, Q, false);
+            bool shaped;
+            if (use_rec()) {
+                const FlatGraph::RowRec rt = lrec(cc);
+                nc = ((rt.flags & (FlatGraph::RR_SUCC_OK | FlatGraph::RR_HAS_C1)) == FlatGraph::RR_SUCC_OK) ? (uint32_t)rt.c0 : EX_NIL;   // the single successor, not the end row
+                nsym = rt.sym0;
+                shaped = probe_setup_rec(rt, nj, P, Q, false);
+            } else {
+                const uint32_t s0 = gld(&G.succ_off[cc]), s1 = gld(&G.succ_off[cc + 1]);
+                nc = s1 - s0 == 1 ? gld(&G.succ[s0]) : EX_NIL;
+                shaped = probe_setup(cc, nj, P, Q, false);
+            }
             const bool walk_on = shaped && nc != EX_NIL && nc != G.end_row && nj < L && nj + 2 < W.pitch;
             uint32_t n0 = EX_INF, n1 = EX_INF, n2 = EX_INF;
             if (shaped) { probe_load(P); probe_load(Q); }
@@ -1133,7 +1179,7 @@ public:
                 if (dfa_events(g, R, end_score)) return true;
                 break;
             }
-            if (gld(&G.sym[nc]) != seq[nj]) {
+            if ((use_rec() ? nsym : (uint32_t)gld(&G.sym[nc])) != seq[nj]) {
                 const uint32_t xm = g + C.x, xg = g + C.o + C.e;
                 if (xm < n0) { wr(nc, nj + 1, EX_ST_M, xm); queue_state(nc, nj + 1, EX_ST_M, xm); }
                 if (xg < n1) { wr(cc, nj + 1, EX_ST_I, xg); queue_state(cc, nj + 1, EX_ST_I, xg); }

@@ -24,27 +24,24 @@ enum : uint8_t {
 };
 constexpr uint32_t ROW_NEAR = 32;
 
-// Layout of the table the replayed search fills (and the traceback of that pass reads): 8 x 8-cell tiles holding the three
-// states of their cells together — [tile row][tile column][state][row & 7][offset & 7] — the dense equivalent of the
-// reference's 8 x 8 blocks (gap_affine.rs:435-446).  The search walks diagonals, rows and columns: within a tile they stay
-// in three 256-byte blocks instead of touching a new line per step.  Rows beyond the last full tile row keep the plain
-// [state][row][offset] layout in the space that is left, so the table fits the 3 * rows * pitch elements of a query.
+// Layout of the table the replayed search fills (and the traceback of that pass reads): [row][offset][state] — the three states
+// of a cell side by side (12 bytes), rows of `pitch` cells.  The replay is bound by instruction issue, not by memory (DESIGN.md
+// §4): an index costs a multiply-add and a shift-add, the state is an immediate offset of the access, and the cells of a
+// relaxation (same row or the row below, offsets j / j + 1) share their address arithmetic.  Rounds 1-2 kept 8 x 8-cell tiles —
+// the reference's blocks, gap_affine.rs:435-446 — for their locality; their index arithmetic cost a tenth of the kernel (0.884 ->
+// 0.785 s on configs[1]; plain [state][row][offset] planes: 0.80 s).
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint64_t ex_cell_index(uint32_t row, uint32_t off, uint32_t st, uint32_t n_rows, uint32_t pitch) {
-    const uint32_t rows_t = n_rows & ~7u;
-    if (row < rows_t) return ((uint64_t)(row >> 3) * (pitch >> 3) + (off >> 3)) * 192u + st * 64u + (row & 7u) * 8u + (off & 7u);
-    return 3ull * rows_t * pitch + ((uint64_t)st * (n_rows - rows_t) + (row - rows_t)) * pitch + off;
+    return ((uint64_t)row * pitch + off) * 3u + st;
 }
 // the same index in 32-bit arithmetic, for tables of fewer than 2^32 elements (the replay kernels check that)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline uint32_t ex_cell_index32(uint32_t row, uint32_t off, uint32_t st, uint32_t n_rows, uint32_t pitch) {
-    const uint32_t rows_t = n_rows & ~7u;
-    if (row < rows_t) return ((row >> 3) * (pitch >> 3) + (off >> 3)) * 192u + st * 64u + (row & 7u) * 8u + (off & 7u);
-    return 3u * rows_t * pitch + (st * (n_rows - rows_t) + (row - rows_t)) * pitch + off;
+    return (row * pitch + off) * 3u + st;
 }
 
 // Compact layout of one query, in 2-byte elements: [M: rows * pitch][4 flag bits per cell: rows * pitch / 4][kept D rows:

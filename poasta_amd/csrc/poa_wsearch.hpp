@@ -35,6 +35,7 @@ struct WSearchParams {
     uint32_t* ring_global;    // null: the rings live in LDS; else [slots * 3 * win] in global memory
     uint32_t graph_lds;       // bytes of the staged graph arrays (exact_lds_bytes), 0: read them from global memory
     uint32_t waves_per_block;
+    uint32_t rec_lds;         // bytes of dynamic LDS behind graph_lds that hold the per-row records (0: not staged)
     uint32_t max_lanes;       // entries tested per step (<= 63)
     uint32_t adapt_lanes;     // 0: always max_lanes; else the step after an expansion tests this many, and a run that used up its lanes four times as many
     uint32_t group;           // lanes per query: 64 (one query per wave), 32, 16 or 8
@@ -86,12 +87,15 @@ __device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
         G.dist_max = reinterpret_cast<const uint32_t*>(stage(E.G.dist_max, 4ull * n));
         G.exit_idx = reinterpret_cast<const uint32_t*>(stage(E.G.exit_idx, 4ull * n));
         G.nbm = reinterpret_cast<const FlatGraph::NodeBubble*>(stage(E.G.nbm, sizeof(FlatGraph::NodeBubble) * (uint64_t)E.n_nbm));
+        // the per-row records of the one-round-trip path, behind the graph arrays (P.rec_lds bytes; 0: that path reads the arrays)
+        if (P.rec_lds) G.rec = reinterpret_cast<const FlatGraph::RowRec*>(stage(E.G.rec, sizeof(FlatGraph::RowRec) * (uint64_t)n));
     }
+    if (!P.rec_lds) G.rec = nullptr;
     // (the wave index is uniform: say so, and every per-query pointer below lives in scalar registers)
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // descriptor rings of this wave (one per query it carries): LDS, or (a priority range too wide for it) slices of P.ring_global
     const uint32_t qpw = 64u / P.group;   // queries per wave
-    uint32_t* ring = P.ring_global ? nullptr : reinterpret_cast<uint32_t*>(lds + P.graph_lds) + (uint64_t)wave * qpw * 3 * P.win;
+    uint32_t* ring = P.ring_global ? nullptr : reinterpret_cast<uint32_t*>(lds + P.graph_lds + P.rec_lds) + (uint64_t)wave * qpw * 3 * P.win;
     const uint32_t slot0 = (blockIdx.x * P.waves_per_block + wave) * qpw;   // first query slot of this wave
     if (P.ring_global && slot0 < P.E.n_queries) ring = P.ring_global + (uint64_t)slot0 * 3 * P.win;
     if (ring) {
@@ -103,7 +107,7 @@ __device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
     // graph arrays and descriptor ring both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers
     const bool lds_all = P.graph_lds && !P.ring_global;
     if constexpr (!GROUPS) {
-        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_NO_SPEC>(P, G, ring, lane, wave);
+        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_REC_LDS | EX_AS_NO_SPEC>(P, G, ring, lane, wave);
         else ws_search_query<EX_AS_NO_SPEC>(P, G, ring, lane, wave);
     } else {
         // (the host asks for groups only with graph and rings in LDS)

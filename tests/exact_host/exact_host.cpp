@@ -14,13 +14,15 @@
 
 using namespace poa_amd;
 
-static uint32_t g_batch = 0, g_win = 0, g_par_lanes = 0, g_par_rmax = 4, g_par_fast = 1;   // g_par_rmax == 0: the flat schedule (run_flat)
+static uint32_t g_batch = 0, g_win = 0, g_par_lanes = 0, g_par_rmax = 4, g_par_fast = 1, g_rec = 0;   // g_par_rmax == 0: the flat schedule (run_flat)
 
 extern "C" {
 
 // 0: linked-list queue (ExactSearch::run); n > 0: bucket queue stepped in batches of n (ExactSearch::run_buckets)
 void exact_host_set_batch(uint32_t n) { g_batch = n; }
 void exact_host_set_window(uint32_t w) { g_win = w; }  // 0: a window that always suffices
+// 1: the instantiation of the wave kernels whose one-round-trip path reads the per-row records (EX_AS_NO_SPEC | EX_AS_REC_LDS), run_buckets
+void exact_host_set_records(uint32_t on) { g_rec = on; }
 // lanes > 0: ExactSearch::run_parallel(lanes, rmax) — the step schedule of poa_psearch.hpp (entries of a stack expanded at once)
 void exact_host_set_parallel(uint32_t lanes, uint32_t rmax, uint32_t use_fast) { g_par_lanes = lanes; g_par_rmax = rmax; g_par_fast = use_fast; }
 
@@ -64,6 +66,23 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     }
     ExactCosts EC{x, o, e, (uint32_t)heuristic, (uint32_t)prune, 0, 0, 0, 0, 0, 0};
     if (span && span[0]) { EC.ends_free = 1; EC.qfe_kind = span[1]; EC.qfe_val = span[2]; EC.gfb_kind = span[3]; EC.gfe_kind = span[4]; EC.gfe_val = span[5]; }
+    if (g_rec && g_batch && !g_par_lanes) {
+        ExactSearchT<EX_AS_NO_SPEC | EX_AS_REC_LDS> S2(G, W, seq, len, EC);
+        const ExactResult R2 = S2.run_buckets(g_batch);
+        out[0] = R2.score; out[1] = R2.num_queued; out[2] = R2.num_visited; out[3] = R2.num_pruned;
+        if (span) { out[4] = g.rows[R2.end_row].node; out[5] = R2.end_off; }
+        if (pm) {
+            for (uint32_t v = 0; v < n; ++v) {
+                const uint32_t r = g.node_row[v];
+                for (uint32_t j = 0; j <= len; ++j) {
+                    pm[(size_t)v * (len + 1) + j] = T[ex_cell_index(r, j, EX_ST_M, g.n, pitch)];
+                    pi[(size_t)v * (len + 1) + j] = T[ex_cell_index(r, j, EX_ST_I, g.n, pitch)];
+                    pd[(size_t)v * (len + 1) + j] = T[ex_cell_index(r, j, EX_ST_D, g.n, pitch)];
+                }
+            }
+        }
+        return (int)R2.status;
+    }
     ExactSearch S(G, W, seq, len, EC);
     ExactResult R = g_par_lanes ? (g_par_rmax ? S.run_parallel(g_par_lanes, g_par_rmax, g_par_fast != 0) : S.run_flat(g_par_lanes, g_par_fast != 0, g_par_fast == 2)) : g_batch ? S.run_buckets(g_batch) : S.run();
     if (getenv("EXH_VERBOSE")) fprintf(stderr, "chunks used %u of %u, status %u, fast-path tests %u, queued %u\n", S.bq_chunk_top, W.bq_chunk_cap, R.status, S.n_fast, R.num_queued);

@@ -33,12 +33,13 @@ def harness():
     X.exact_host_bubbles.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp] * 5 + [C.c_uint32]
     X.exact_host_set_batch.argtypes = [C.c_uint32]
     X.exact_host_set_parallel.argtypes = [C.c_uint32] * 3
+    X.exact_host_set_records.argtypes = [C.c_uint32]
     X.exact_host_run2.argtypes = [C.c_uint32] * 3 + [vp] * 5 + [vp, C.c_int, C.c_int, vp, C.c_uint32, vp, vp, vp]
     return X
 
 
-@pytest.fixture(params=[0, 1, 7, 64, (63, 4, 1), (5, 1, 1), (63, 8, 0), (8, 0, 1), (8, 0, 2), (63, 0, 2), (3, 0, 2), (16, 0, 0)],
-                ids=["linked_list_queue", "buckets_batch1", "buckets_batch7", "buckets_batch64", "parallel_63x4", "parallel_5x1",
+@pytest.fixture(params=[0, 1, 7, 64, "records_batch7", (63, 4, 1), (5, 1, 1), (63, 8, 0), (8, 0, 1), (8, 0, 2), (63, 0, 2), (3, 0, 2), (16, 0, 0)],
+                ids=["linked_list_queue", "buckets_batch1", "buckets_batch7", "buckets_batch64", "buckets_batch7_row_records", "parallel_63x4", "parallel_5x1",
                      "parallel_63x8_generic_code", "flat_8", "flat_8_lean", "flat_63_lean", "flat_3_lean", "flat_16_generic_code"])
 def queue_variant(request, harness):
     """0: ExactSearch::run (linked-list queue, the one-search-per-lane kernel); n: ExactSearch::run_buckets(n), the
@@ -48,9 +49,14 @@ def queue_variant(request, harness):
     pop order, one per lane; fast == 2: the lean step, greedy extensions resumed from step to step)."""
     if isinstance(request.param, tuple):
         harness.exact_host_set_parallel(*request.param)
+    elif request.param == "records_batch7":
+        # the wave kernels' instantiation whose one-round-trip path reads the per-row records (successors, symbols, bubbles)
+        harness.exact_host_set_batch(7)
+        harness.exact_host_set_records(1)
     else:
         harness.exact_host_set_batch(request.param)
     yield request.param
+    harness.exact_host_set_records(0)
     harness.exact_host_set_batch(0)
     harness.exact_host_set_parallel(0, 4, 1)
 
