@@ -942,6 +942,8 @@ public:
         return !((P.on && P.t + 1 >= W.pitch) || (Q.on && Q.t + 1 >= W.pitch));
     }
     // both tests: 0 can improve, 2 pruned, 3 undecided (the generic code decides)
+    // (a branch-free restatement of probe_decide — selects instead of its nested conditions — was measured 2.5 % SLOWER in the
+    // wave kernel: most probes leave at one of the early exits)
     POA_HD uint32_t probe_decide2(const Probe& P, const Probe& Q, uint32_t g, uint32_t st) {
         const uint32_t r = probe_decide(P, g, st);
         if (r != 0 || !Q.on) return r;
@@ -1032,27 +1034,38 @@ public:
     // The shape: one or two successors, none of them the end row (an Insertion state: any), for a Match state query symbols left
     // and a second successor that does not match; the bubbles decide only HOW the pruning test is made (probes, else the
     // generic code).
-    POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
+    POA_HD uint32_t inspect_fast(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) { return inspect_fast_t<false>(g, v, j, st, F); }
+    // RANGE: also the bubbles whose paths differ in length (the range form of the test: three dependent loads).  The wave kernel
+    // keeps that out of the test its lanes run together — every lane would wait for the one that has such a row — and
+    // asks again with RANGE for the entry its run stopped at.
+    template <bool RANGE>
+    POA_HD uint32_t inspect_fast_t(uint32_t g, uint32_t v, uint32_t j, uint32_t st, FastItem& F) {
         F.kind = 0;
         if constexpr (TP) return 3;   // (two-piece model: the generic code)
         uint32_t c, c1, kind = 1;
         Probe P, Q;
-        bool probes;
+        bool probes, use_range = false;
+        FlatGraph::RowRec rr_keep{};
         if (use_rec()) {
             // everything the test needs to know of the row in one record: successors, their symbols, the bubbles ahead
             const FlatGraph::RowRec rr = lrec(v);
             const uint32_t fl = rr.flags;
-            if (C.ends_free || (fl & FlatGraph::RR_END) || rr.c0 == 0xFFFFu || (st != EX_ST_I && !(fl & FlatGraph::RR_SUCC_OK)) || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) return 3;
+            if (C.ends_free || (fl & FlatGraph::RR_END) || rr.c0 == 0xFFFFu || (st != EX_ST_I && !(fl & FlatGraph::RR_SUCC_OK)) || W.swpn != 1 || j + 2 >= W.pitch || g >= 0xFFFF0000u) { EXD((st != EX_ST_I && !(fl & FlatGraph::RR_SUCC_OK) && !(fl & FlatGraph::RR_END)) ? 1 : 2, st); return 3; }
             c = rr.c0;
             c1 = ((fl & FlatGraph::RR_HAS_C1) && st != EX_ST_I) ? (uint32_t)rr.c1 : EX_NIL;
             if (st == EX_ST_M) {
-                if (j >= L) return 3;
-                if (j == 0 && L != 0 && rr.sym == seq[0]) return 3;   // the offset-0 special case, dfa.rs:146-167
+                if (j >= L) { EXD(4, st); return 3; }
+                if (j == 0 && L != 0 && rr.sym == seq[0]) { EXD(4, st); return 3; }   // the offset-0 special case, dfa.rs:146-167
                 const uint8_t qc = seq[j];
                 if (rr.sym0 == qc) kind = 2;
-                if (c1 != EX_NIL && rr.sym1 == qc) return 3;
+                if (c1 != EX_NIL && rr.sym1 == qc) { EXD(1, st); return 3; }
             }
             probes = probe_setup_rec(rr, j, P, Q, true);
+            if (RANGE && !probes && (fl & FlatGraph::RR_PROBE_OK)) {
+                // bubbles whose paths differ in length by one or two (an inserted branch ahead): the range form of the test
+                // (three dependent loads instead of one round trip; the generic code costs several times that)
+                use_range = true; rr_keep = rr;
+            }
         } else {
         const uint32_t s0 = gld(&G.succ_off[v]), s1 = gld(&G.succ_off[v + 1]);
         const uint32_t ns = s1 - s0;
@@ -1071,7 +1084,13 @@ public:
         }
         probes = probe_setup(v, j, P, Q, true);
         }
-        if constexpr ((AS & EX_AS_NO_SPEC) != 0) { if (!probes) { EXD(3, st); return 3; } }   // (wave kernels: the generic code takes it, nothing loaded twice)
+        LProbe R0, R1;
+        if constexpr ((AS & EX_AS_NO_SPEC) != 0) {
+            if (use_range) {
+                lp_setup(R0, rr_keep, 0, j, C.prune != 0); lp_setup(R1, rr_keep, 1, j, C.prune != 0);
+                if ((R0.on && R0.tmax + 1 >= W.pitch) || (R1.on && R1.tmax + 1 >= W.pitch)) { EXD(3, st); return 3; }
+            } else if (!probes) { EXD(3, st); return 3; }   // (wave kernels: the generic code takes it, nothing loaded twice)
+        }
         // ---- every load of the step, before any use ----
         const uint32_t i_own = cix(v, j, st);
         uint32_t i0, i1, i2 = i_own, i3 = i_own, i4 = i_own;
@@ -1082,6 +1101,7 @@ public:
         uint32_t t0 = W.T[i0], t1 = W.T[i1], t2 = st == EX_ST_M ? W.T[i2] : EX_INF;
         uint32_t t3 = c1 != EX_NIL ? W.T[i3] : EX_INF, t4 = (c1 != EX_NIL && st == EX_ST_M) ? W.T[i4] : EX_INF;
         if (probes) { probe_load(P); probe_load(Q); }
+        if (use_range) { lp_load1(R0); lp_load1(R1); }
         if (in_spec()) {
             // (the probes note what they looked at when they decide)
             note_cell(i_own); note_cell(i0); if (st != EX_ST_I || j < L) note_cell(i1); if (st == EX_ST_M) note_cell(i2);
@@ -1095,6 +1115,11 @@ public:
         n_fast += 1;
         if (g > own) return 1;                      // stale (astar.rs:146)
         uint32_t r = probes ? probe_decide2(P, Q, g, st) : 3u;
+        if (use_range) {
+            lp_locate1(R0); lp_locate1(R1); lp_load2(R0); lp_load2(R1); lp_locate2(R0); lp_locate2(R1); lp_load3(R0); lp_load3(R1);
+            r = lp_decide(R0, g, st);
+            if (r == 0) r = lp_decide(R1, g, st);
+        }
         if constexpr ((AS & EX_AS_NO_SPEC) != 0) { if (r == 3) { EXD(probes ? 5 : 3, st); return 3; } }   // (wave kernel: the entry's own lane takes the generic code after the run)
         if (r == 3) { PF_TICK(1); r = (C.prune && prune(g, v, j, st)) ? 2u : 0u; PF_TICK(5); }   // bubbles of another shape: the generic test (astar.rs:155)
         if (err) return 3;
@@ -1298,6 +1323,7 @@ public:
             for (uint32_t i = 0; i < nb && !err; ++i) {
                 e = ch[d.n_top - i];
                 uint32_t sk = use_fast ? inspect_fast(e.x, e.y, e.z, st, F) : 3u;
+                if (sk == 3 && use_fast && use_rec() && !err) sk = inspect_fast_t<true>(e.x, e.y, e.z, st, F);   // (the wave kernel's second ask)
                 if (sk == 3) sk = inspect_skip(e.x, e.y, e.z, st);
                 if (sk == 0) { n = i; break; }
                 if (sk == 2) num_pruned += 1;

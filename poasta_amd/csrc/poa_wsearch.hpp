@@ -323,9 +323,14 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
                 S.bq_wr = true;
                 if (F.kind) found = S.process_fast(e.x, e.y, e.z, st, F, R, end_score) ? 1u : 0u;
                 else {
+                    // a row whose bubbles need the range form of the test: asked here, by the entry's own lane alone
+                    if (sk == 3 && S.use_rec()) sk = S.template inspect_fast_t<true>(e.x, e.y, e.z, st, F);
+                    if (sk == 0 && F.kind && !S.err) found = S.process_fast(e.x, e.y, e.z, st, F, R, end_score) ? 1u : 0u;
+                    else {
                     if (sk == 3) sk = S.inspect_skip(e.x, e.y, e.z, st);
                     if (sk == 2) S.num_pruned += 1;
                     if (sk == 0 && !S.err) found = S.process_popped(e.x, e.y, e.z, st, R, end_score) ? 1u : 0u;
+                    }
                 }
                 S.bq_wr = lane == 0;
             }

@@ -69,6 +69,12 @@ int exact_host_run(uint32_t n, uint32_t start, uint32_t end, const uint8_t* symb
     if (g_rec && g_batch && !g_par_lanes) {
         ExactSearchT<EX_AS_NO_SPEC | EX_AS_REC_LDS> S2(G, W, seq, len, EC);
         const ExactResult R2 = S2.run_buckets(g_batch);
+#if defined(POA_EXACT_DIAG)
+        if (getenv("EXH_VERBOSE")) {
+            const char* why[8] = {"stale/pruned on the fast path", "several successors", "end row / misc", "bubble shape", "Match special", "probe undecided", "fast expand", "fast greedy walk"};
+            for (int r = 0; r < 8; ++r) fprintf(stderr, "  %-32s M %8u  D %8u  I %8u\n", why[r], S2.diag[r][0], S2.diag[r][1], S2.diag[r][2]);
+        }
+#endif
         out[0] = R2.score; out[1] = R2.num_queued; out[2] = R2.num_visited; out[3] = R2.num_pruned;
         if (span) { out[4] = g.rows[R2.end_row].node; out[5] = R2.end_off; }
         if (pm) {
