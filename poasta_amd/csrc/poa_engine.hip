@@ -1006,7 +1006,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                 wp.ring_global = nullptr;
                 if (!ring_lds) wp.ring_global = b->d_ex_head.p;  // [slots * 3 * ex_n_prio] holds slots * 3 * win
                 const uint32_t lds_bytes = wp.graph_lds + wp.rec_lds + (uint32_t)ring_bytes;
-                const void* kfn = group == 64 ? reinterpret_cast<const void*>(poa_wsearch_kernel) : reinterpret_cast<const void*>(poa_wsearch_groups_kernel);
+                const bool lds_all = wp.graph_lds && !wp.ring_global;   // (else the kernel whose search reads through generic pointers)
+                const void* kfn = group != 64 ? reinterpret_cast<const void*>(poa_wsearch_groups_kernel)
+                                              : (lds_all ? reinterpret_cast<const void*>(poa_wsearch_kernel) : reinterpret_cast<const void*>(poa_wsearch_global_kernel));
                 if (lds_bytes > 48u * 1024u)
                     HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 const uint32_t per_block = wpb * (64 / group);
@@ -1018,7 +1020,7 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                     // one small copy behind the dense pass of this chunk.
                     int per_cu = 1, cus = 256;
                     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(poa_wsearch_kernel), (int)(64 * wpb), lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, (int)(64 * wpb), lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
                     const uint32_t resident = (uint32_t)cus * (uint32_t)per_cu;
                     if (n_blocks > resident) {
                         std::vector<uint32_t> sc(ch.count), ord(ch.count);
@@ -1034,8 +1036,9 @@ int poa_batch_run_ex(poa_batch_t* b, const poa_costs_t* costs, const poa_config_
                         n_blocks = resident;
                     }
                 }
-                if (group == 64) hipLaunchKernelGGL(poa_wsearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
-                else hipLaunchKernelGGL(poa_wsearch_groups_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
+                if (group != 64) hipLaunchKernelGGL(poa_wsearch_groups_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
+                else if (lds_all) hipLaunchKernelGGL(poa_wsearch_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
+                else hipLaunchKernelGGL(poa_wsearch_global_kernel, dim3(n_blocks), dim3(64 * wpb), lds_bytes, stream, wp);
             } else {
             // active lanes per wave: one sequential search per lane.  Few lanes = little divergence but many
             // waves; enough waves to fill the chip (~16 per CU) first, then more lanes per wave.

@@ -62,8 +62,12 @@ __device__ __forceinline__ void ws_search_groups(const WSearchParams& P, const E
 
 // graph staging + ring set-up shared by the two kernels; GROUPS: several queries per wave (its own kernel, so that the
 // default one-query-per-wave kernel keeps its registers: the union of both needs scratch)
-template <bool GROUPS>
+// MODE 0: one query per wave, graph arrays + records + descriptor rings in LDS (the default); 1: several queries per wave;
+// 2: one query per wave with whatever does not fit read through generic pointers.  Three kernels, so that each keeps its
+// registers (the union of two instantiations of the search in one kernel spills for both).
+template <int MODE>
 __device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
+    constexpr bool GROUPS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const ExactParams& E = P.E;
     ExactGraph G = E.G;
@@ -106,9 +110,10 @@ __device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
     if (slot0 >= P.E.n_queries) return;
     // graph arrays and descriptor ring both in LDS: typed LDS accesses (no FLAT instructions); else generic pointers
     const bool lds_all = P.graph_lds && !P.ring_global;
-    if constexpr (!GROUPS) {
-        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_REC_LDS | EX_AS_NO_SPEC>(P, G, ring, lane, wave);
-        else ws_search_query<EX_AS_NO_SPEC>(P, G, ring, lane, wave);
+    if constexpr (MODE == 0) {
+        if (lds_all) ws_search_query<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_REC_LDS | EX_AS_NO_SPEC>(P, G, ring, lane, wave);   // (the host launches this kernel only then)
+    } else if constexpr (MODE == 2) {
+        ws_search_query<EX_AS_NO_SPEC>(P, G, ring, lane, wave);
     } else {
         // (the host asks for groups only with graph and rings in LDS)
         if (P.group == 32) ws_search_groups<EX_AS_GRAPH_LDS | EX_AS_RING_LDS | EX_AS_NO_SPEC, 32>(P, G, ring, lane, wave);
@@ -117,8 +122,9 @@ __device__ __forceinline__ void ws_kernel_body(const WSearchParams& P) {
     }
 }
 
-__global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) { ws_kernel_body<false>(P); }
-__global__ __launch_bounds__(1024) void poa_wsearch_groups_kernel(WSearchParams P) { ws_kernel_body<true>(P); }
+__global__ __launch_bounds__(1024) void poa_wsearch_kernel(WSearchParams P) { ws_kernel_body<0>(P); }
+__global__ __launch_bounds__(1024) void poa_wsearch_groups_kernel(WSearchParams P) { ws_kernel_body<1>(P); }
+__global__ __launch_bounds__(1024) void poa_wsearch_global_kernel(WSearchParams P) { ws_kernel_body<2>(P); }
 
 
 
