@@ -362,6 +362,7 @@ public:
 
     // ---- reached sets: BTreeSet<offset> per exit node as a two-level bitset (gap_affine.rs:711,:767-773) ---
     POA_HD void mark_word(uint32_t x, uint32_t off) {   // the write itself (direct mode; commit of a logged mark)
+        if (!mark_on) return;   // (wave kernel: sections every lane executes alike — one lane sets the mark)
         const uint32_t wi = off >> 6;
         uint64_t* w = W.reached + (uint64_t)x * W.wpn + wi;
         uint64_t* sm = W.rsum + (uint64_t)x * W.swpn + (wi >> 6);
@@ -561,6 +562,7 @@ public:
     // Freed chunks go on a free list threaded through slot 0.
     uint32_t bq_live = 0, bq_chunk_top = 0, bq_hi = 0, bq_free = EX_NIL;
     bool bq_wr = true;  // wave kernel: in the sections every lane executes alike, only one lane stores
+    bool mark_on = true;   // same for the reached marks (atomics: sixty-four of them on one word otherwise)
     POA_HD uint32_t bq_alloc() {
         if (bq_free != EX_NIL) { const uint32_t c = bq_free; bq_free = W.bq_chunks[(uint64_t)BQ_CHUNK * c].x; return c; }
         if (bq_chunk_top >= W.bq_chunk_cap || bq_chunk_top >= (1u << 26)) { err = EX_POOL_FULL; return EX_NIL; }

@@ -21,6 +21,12 @@
 // ExactSearch::run_buckets (poa_exact.hpp) is the same schedule one lane at a time; compiled for the host it is diffed
 // against the oracle (tests/test_exact_replay.py), and this kernel is diffed against both on the GPU.
 #pragma once
+// 1: everything outside the test of the entries runs on every lane with the same values (scalar branches instead of one lane's
+// divergent code and a broadcast of the state afterwards).  Built, bit-identical on the GPU tests, measured 11 % SLOWER on
+// configs[1] (0.775 s against 0.698 s): sixty-four lanes' worth of addresses per load and store, and 35 more spilled registers.
+#if !defined(POA_WS_UNIFORM)
+#define POA_WS_UNIFORM 0
+#endif
 #include <hip/hip_runtime.h>
 
 #include "poa_exact_kernel.hpp"
@@ -289,9 +295,20 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
         R.end_row = ws_bcast(R.end_row, from);
         R.end_off = ws_bcast(R.end_off, from);
     };
+#if POA_WS_UNIFORM
+    // Everything outside the test of the entries runs on EVERY lane with the same values (the popped entry and what its test
+    // found are broadcast from its lane): uniform control flow — scalar branches, no exec-mask bookkeeping, no copies where
+    // divergent paths merge, which is what the single-lane form of this code mostly consisted of.  Only lane 0 stores to the
+    // queue and sets marks (bq_wr); table cells are stored by all lanes alike (same address, same value).
+    (void)adopt;
+    S.bq_wr = lane == 0; S.mark_on = lane == 0;
+    S.push_initial_states();
+    uint32_t pruned_lane = 0;   // per-lane tally of the entries the test found pruned
+#else
     if (lane == 0) S.push_initial_states();
     adopt(0);
     S.bq_wr = lane == 0;
+#endif
 
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool prof = P.prof != nullptr;
@@ -318,6 +335,37 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
         // the next step: after an expansion what lies on top was just pushed (rarely stale): few lanes — each tested entry costs
         // loads and its own branch of the test; a run of stale / pruned entries that used up its lanes goes on wider
         if (P.adapt_lanes) { lanes_now = n < nb ? P.adapt_lanes : 4 * lanes_now; if (lanes_now > P.max_lanes) lanes_now = P.max_lanes; }
+#if POA_WS_UNIFORM
+        if (lane < n && sk == 2) pruned_lane += 1;
+        S.err = n < nb ? ws_bcast(S.err, n) : 0u;     // what the run's last test hit; tests beyond the run are discarded
+        const uint32_t prev = ws_bcast(e.x, 63);      // lane 63 is never active (nb <= 63)
+        S.bq_drop(st, d, n < nb ? n + 1 : nb, prev);
+        steps += 1;
+        WS_TICK(2);
+        if (n < nb && !S.err) {
+            const uint32_t ux = ws_bcast(e.x, n), uy = ws_bcast(e.y, n), uz = ws_bcast(e.z, n);
+            typename ExactSearchT<AS>::FastItem Fu{ws_bcast(F.kind, n), ws_bcast(F.c, n), ws_bcast(F.c1, n), ws_bcast(F.t0, n), ws_bcast(F.t1, n),
+                                                   ws_bcast(F.t2, n), ws_bcast(F.t3, n), ws_bcast(F.t4, n)};
+            uint32_t sku = ws_bcast(sk, n);
+            const uint32_t kind0 = Fu.kind;
+            if (Fu.kind) found = S.process_fast(ux, uy, uz, st, Fu, R, end_score) ? 1u : 0u;
+            else {
+                // a row whose bubbles need the range form of the test: asked here
+                if (sku == 3 && S.use_rec()) sku = S.template inspect_fast_t<true>(ux, uy, uz, st, Fu);
+                if (sku == 0 && Fu.kind && !S.err) found = S.process_fast(ux, uy, uz, st, Fu, R, end_score) ? 1u : 0u;
+                else {
+                    if (sku == 3) sku = S.inspect_skip(ux, uy, uz, st);
+                    if (sku == 2) S.num_pruned += 1;
+                    if (sku == 0 && !S.err) found = S.process_popped(ux, uy, uz, st, R, end_score) ? 1u : 0u;
+                }
+            }
+            if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WS_TICK(kind0 ? 3 : 4); pc[kind0 ? 5 : 6] += 1; }
+        }
+    }
+
+    // (the counters of the uniform part hold the same value in every lane)
+    const uint32_t nq = S.num_queued, nv = S.num_visited, np = S.num_pruned + ws_wave_sum(pruned_lane);
+#else
         if (lane < n && sk == 2) S.num_pruned += 1;   // per-lane tallies, summed at the end
         if (lane > n) S.err = 0;                      // tests beyond the run are discarded with whatever they hit
         const uint32_t prev = ws_bcast(e.x, 63);      // lane 63 is never active (nb <= 63)
@@ -346,6 +394,7 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
     }
 
     const uint32_t nq = ws_wave_sum(S.num_queued), nv = ws_wave_sum(S.num_visited), np = ws_wave_sum(S.num_pruned);
+#endif
     if (lane == 0) {
         E.status[qi] = S.err ? S.err : (found ? EX_OK : EX_PANIC);
         E.end_cell[2 * qi] = R.end_row;
