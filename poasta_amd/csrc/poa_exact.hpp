@@ -468,8 +468,20 @@ public:
     // ---- heuristic (heuristic.rs:70-102 / :41-46) --------------------------------------------
     POA_HD uint32_t h(uint32_t row, uint32_t off, uint32_t st) const {
         if (C.heuristic == EX_H_DIJKSTRA) return 0;
-        uint32_t mn = gld(&G.dist_min[row]); mn = mn ? mn - 1 : 0;
-        uint32_t mx = gld(&G.dist_max[row]); mx = mx ? mx - 1 : 0;
+        uint32_t mn, mx;
+        if (use_rec()) {
+            // (dmin | dmax << 16 of the row's record: one 4-byte load, already minus one)
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+            const uint32_t dd = ((lds_cu32*)G.rec)[8 * row + 4];
+#else
+            const uint32_t dd = (uint32_t)G.rec[row].dmin | ((uint32_t)G.rec[row].dmax << 16);
+#endif
+            mn = dd & 0xFFFFu; mx = dd >> 16;
+        } else {
+        mn = gld(&G.dist_min[row]); mn = mn ? mn - 1 : 0;
+        mx = gld(&G.dist_max[row]); mx = mx ? mx - 1 : 0;
+        }
         const uint32_t tmin = off + mn, tmax = off + mx;
         uint32_t gap;
         if (tmin > L) { gap = tmin - L; if (st != EX_ST_D) st = EX_ST_M; }

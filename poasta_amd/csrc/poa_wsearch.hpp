@@ -291,9 +291,7 @@ __device__ __forceinline__ void ws_search_query(const WSearchParams& P, const Ex
         S.bq_chunk_top = ws_bcast(S.bq_chunk_top, from);
         S.bq_free = ws_bcast(S.bq_free, from);
         found = ws_bcast(found, from);
-        end_score = ws_bcast(end_score, from);
-        R.end_row = ws_bcast(R.end_row, from);
-        R.end_off = ws_bcast(R.end_off, from);
+        if (found) { end_score = ws_bcast(end_score, from); R.end_row = ws_bcast(R.end_row, from); R.end_off = ws_bcast(R.end_off, from); }
     };
 #if POA_WS_UNIFORM
     // Everything outside the test of the entries runs on EVERY lane with the same values (the popped entry and what its test
