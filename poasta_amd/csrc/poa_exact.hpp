@@ -273,9 +273,11 @@ public:
     }
     POA_HD uint32_t cix(uint32_t row, uint32_t off, uint32_t st) const {
         if constexpr (TP) {
-            // five plain planes in the order the two-piece traceback reads them (poa_twopiece.hpp): M, I1, D1, I2, D2
+            // [row][offset][state], the five states of a cell side by side in the order of the two-piece planes (M, I1, D1, I2, D2;
+            // poa2_traceback_kernel reads it through ex2_cell_index): this search lives on the latency of dependent loads, and
+            // the cells of an expansion — (v, j) and (v, j + 1), or the same offset one row on — share their cache lines
             const uint32_t pl = st == EX_ST_M ? 0u : st == EX_ST_I ? 1u : st == EX_ST_D ? 2u : st == EX_ST_I2 ? 3u : 4u;
-            return (pl * W.n_rows + row) * W.pitch + off;
+            return (row * W.pitch + off) * 5u + pl;
         } else return ex_cell_index32(row, off, st, W.n_rows, W.pitch);
     }
     // visited score of a cell inside the table

@@ -257,7 +257,10 @@ __global__ __launch_bounds__(64) void poa2_traceback_kernel(TwoPieceParams P) {
     const uint64_t plane = (uint64_t)P.n_rows * P.pitch;
     const T* base = reinterpret_cast<const T*>(P.planes) + (uint64_t)slot * 5 * plane;
     enum : uint32_t { SM = 0, SI = 1, SD = 2, SI2 = 3, SD2 = 4 };   // plane order
-    auto S = [&](uint32_t row, uint32_t j, uint32_t st) { return PlaneIO<T>::get(base + st * plane + (uint64_t)row * P.pitch + j); };
+    // dense pass: five planes; replayed search (u32): [row][offset][state] (ExactSearchT::cix)
+    auto S = [&](uint32_t row, uint32_t j, uint32_t st) {
+        return P.exact_pass ? PlaneIO<T>::get(base + ((uint64_t)row * P.pitch + j) * 5u + st) : PlaneIO<T>::get(base + st * plane + (uint64_t)row * P.pitch + j);
+    };
     const uint32_t INF = 0xFFFFFFFFu;
     poa_aln_pair_t* out = P.scratch + (uint64_t)slot * P.scratch_stride;
     uint32_t n_out = 0, fl = 0;

@@ -168,7 +168,7 @@ int exact_host_run2(uint32_t n, uint32_t start, uint32_t end, const uint8_t* sym
     if (planes) {
         for (int pl = 0; pl < 5; ++pl)
             for (uint32_t v = 0; v < n; ++v)
-                std::memcpy(planes[pl] + (size_t)v * (len + 1), T.data() + ((size_t)pl * n + g.node_row[v]) * pitch, ((size_t)len + 1) * 4);
+                for (uint32_t j = 0; j <= len; ++j) planes[pl][(size_t)v * (len + 1) + j] = T[((size_t)g.node_row[v] * pitch + j) * 5 + pl];
     }
     return (int)R.status;
 }
