@@ -372,12 +372,14 @@ def test_gpu_exact_overflow_keeps_dense_result(engine, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(POA_WS_RING_GLOBAL="1"), dict(POA_WS_GROUP="16"), dict(POA_WS_GROUP="8", POA_WS_WAVES="2"),
                                  dict(POA_WS_STATIC="1"), dict(POA_WS_LANES="1"), dict(POA_WS_LANES="63", POA_WS_WAVES="4"),
+                                 dict(POA_WS_REC="0"), dict(POA_WS_ADAPT="0", POA_WS_LANES="16"), dict(POA_WS_ADAPT="1", POA_WS_LANES="63"),
                                  dict(POA_EXACT_LDS="0"), dict(POA_EXACT_IMPL="lane"),
                                  dict(POA_EXACT_IMPL="flat"), dict(POA_EXACT_IMPL="flat", POA_PS_LEAN="0"),
                                  dict(POA_EXACT_IMPL="flat", POA_PS_LANES="3", POA_WS_RING_GLOBAL="1"),
                                  dict(POA_EXACT_IMPL="flat", POA_EXACT_LDS="0", POA_WS_STATIC="1")],
                          ids=["ring_in_global_memory", "four_queries_per_wave", "eight_queries_per_wave", "static_schedule",
-                              "one_entry_per_step", "63_entries_per_step", "graph_in_global_memory", "one_search_per_lane_kernel",
+                              "one_entry_per_step", "63_entries_per_step", "test_over_graph_arrays_not_records", "fixed_test_width_16",
+                              "adaptive_width_from_1_to_63", "graph_in_global_memory", "one_search_per_lane_kernel",
                               "flat_schedule_lean_step", "flat_schedule_generic_code", "flat_3_lanes_ring_global", "flat_records_in_global_memory"])
 def test_gpu_replay_variants_are_bit_identical(engine, oracle, env):
     """Every schedule / placement variant of the replay kernels returns the reference's alignments: the descriptor ring in
