@@ -554,6 +554,22 @@ def bench_two_piece(args):
                          "traffic": None,
                          "note": "achieved = 20 B/cell (five u32 planes: the reference's visited cell of this model) x cells / forward time, HIP events inside the "
                                  "call; the engine writes the planes as u16 when the score bound allows (stored_*); PMC traffic: profiles/r03_two_piece/"}}
+    # the model's own search replayed (Affine2PieceMinGapCost + pruning: what the CLI runs), on a sample: queries per second and
+    # how far its scores lie above the dense optimum
+    try:
+        k = min(n, 4096)
+        ex = aligner.PoastaAligner(aligner.Affine2PieceMinGapCost(aligner.GapAffine2Piece(4, 2, 6, 1, 24)), mode="exact")
+        t0 = time.perf_counter()
+        rx = ex.align_batch(g, qseq=qseq[:int(qoff[k])], qoff=qoff[:k + 1], want_pairs=False)
+        dtx = time.perf_counter() - t0
+        dn = al.align_batch(g, qseq=qseq[:int(qoff[k])], qoff=qoff[:k + 1], want_pairs=False)
+        line["bit_exact"] = {"mode": "exact (poa_align_batch_2piece_ex: replay of the five-state search, min-gap heuristic, pruning)", "queries": k,
+                             "seconds": round(dtx, 3), "ms_replay": round(rx.stats["ms_exact"], 1), "queries_per_s": round(k / dtx, 1),
+                             "value": round(int(g.n) * float((np.diff(qoff[:k + 1]).astype(np.int64) + 1).sum()) / dtx / 1e9, 4), "unit": "Gcells/s",
+                             "states_visited_mean": round(float(rx.search_counters[:, 1].mean()), 1), "flagged": int((rx.flags != 0).sum()),
+                             "scores_above_dense_optimum": int((rx.score > dn.score).sum()), "scores_below_dense_optimum": int((rx.score < dn.score).sum())}
+    except Exception as exc:   # (extra: never takes the line down)
+        line["bit_exact"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     print(json.dumps(line), flush=True)
 
 
