@@ -282,8 +282,10 @@ enum class Mode : uint32_t { Dense = POA_MODE_DENSE, Exact = POA_MODE_EXACT, Hyb
 template <typename Config>
 class PoastaAligner {
 public:
-    PoastaAligner(Config config, AlignmentType aln_type, int device = 0, Mode mode = Mode::Dense)
-        : config_(config), aln_type_(aln_type), device_(device), mode_(mode) {}
+    // queue_entries_per_cell: workspace of the replayed search per table cell (0: the engine's default; raise it when a result
+    // comes back with POA_FLAG_EXACT_OVERFLOW)
+    PoastaAligner(Config config, AlignmentType aln_type, int device = 0, Mode mode = Mode::Dense, float queue_entries_per_cell = 0.f)
+        : config_(config), aln_type_(aln_type), device_(device), mode_(mode), queue_entries_per_cell_(queue_entries_per_cell) {}
 
     // mod.rs:114-145
     AstarResult align(const graphs::POAGraph& g, const std::string& seq) const { return align_batch(g, {seq}, true).at(0); }
@@ -305,6 +307,7 @@ public:
         std::vector<poa_aln_pair_t> pairs(cap);
         poa_config_t cfg{};
         cfg.mode = (uint32_t)mode_; cfg.heuristic = Config::heuristic; cfg.pruning = pruning ? 1u : 0u;
+        cfg.queue_entries_per_cell = queue_entries_per_cell_;
         if (aln_type_.ends_free) {
             cfg.span = POA_SPAN_ENDS_FREE;
             cfg.qry_free_begin = poa_bound_t{aln_type_.qry_free_begin.kind, aln_type_.qry_free_begin.value};
@@ -347,6 +350,7 @@ private:
     AlignmentType aln_type_;
     int device_;
     Mode mode_;
+    float queue_entries_per_cell_;
 };
 
 }  // namespace aligner

@@ -79,11 +79,12 @@ int main(int argc, char** argv) {
     try {
         if (argc >= 3 && std::strcmp(argv[1], "replay") == 0) return replay(argv[2]);
         if (argc < 3 || std::strcmp(argv[1], "align") != 0) {
-            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6 | 6,24] [-e 2 | 2,1] [-H mingap|dijkstra] [-m global|semi-global|ends-free] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--device 0] [--alignments file] [--timing file.tsv] reads.fa\n"
+            std::fprintf(stderr, "usage: poasta_align_amd align [-n 4] [-g 6 | 6,24] [-e 2 | 2,1] [-H mingap|dijkstra] [-m global|semi-global|ends-free] [-I graph.msa.fa] [-o out.fa] [--mode dense|exact|hybrid] [--queue-entries-per-cell F] [--device 0] [--alignments file] [--timing file.tsv] reads.fa\n"
                                  "       poasta_align_amd replay alignments.txt\n");
             return 2;
         }
         int mismatch = 4, device = 0;
+        float qepc = 0.f;   // replay workspace per table cell (0: the engine's default)
         std::string open_s = "6", extend_s = "2", heuristic = "mingap", span = "global";
         std::string out_path, msa_path, aln_path, timing_path, mode = "hybrid";
         std::vector<std::string> pos;
@@ -98,6 +99,7 @@ int main(int argc, char** argv) {
             else if (a == "-o") out_path = need("-o");
             else if (a == "-I" || a == "--graph") msa_path = need("-I");
             else if (a == "--mode") mode = need("--mode");
+            else if (a == "--queue-entries-per-cell") qepc = std::stof(need("--queue-entries-per-cell"));
             else if (a == "--device") device = std::stoi(need("--device"));
             else if (a == "--alignments") aln_path = need("--alignments");
             else if (a == "--timing") timing_path = need("--timing");
@@ -134,10 +136,10 @@ int main(int argc, char** argv) {
         const aligner::GapAffine c1((uint8_t)mismatch, (uint8_t)ge[0], (uint8_t)go[0]);
         const aligner::GapAffine2Piece c2 = two_piece ? aligner::GapAffine2Piece((uint8_t)mismatch, (uint8_t)ge[0], (uint8_t)go[0], (uint8_t)ge[1], (uint8_t)go[1])
                                                       : aligner::GapAffine2Piece((uint8_t)mismatch, (uint8_t)ge[0], (uint8_t)go[0], (uint8_t)ge[0], (uint8_t)go[0]);
-        const aligner::PoastaAligner<aligner::AffineMinGapCost> al_m(aligner::AffineMinGapCost(c1), aln_type, device, m);
-        const aligner::PoastaAligner<aligner::AffineDijkstra> al_d(aligner::AffineDijkstra(c1), aln_type, device, m);
-        const aligner::PoastaAligner<aligner::Affine2PieceMinGapCost> al2_m(aligner::Affine2PieceMinGapCost(c2), aln_type, device, m);
-        const aligner::PoastaAligner<aligner::Affine2PieceDijkstra> al2_d(aligner::Affine2PieceDijkstra(c2), aln_type, device, m);
+        const aligner::PoastaAligner<aligner::AffineMinGapCost> al_m(aligner::AffineMinGapCost(c1), aln_type, device, m, qepc);
+        const aligner::PoastaAligner<aligner::AffineDijkstra> al_d(aligner::AffineDijkstra(c1), aln_type, device, m, qepc);
+        const aligner::PoastaAligner<aligner::Affine2PieceMinGapCost> al2_m(aligner::Affine2PieceMinGapCost(c2), aln_type, device, m, qepc);
+        const aligner::PoastaAligner<aligner::Affine2PieceDijkstra> al2_d(aligner::Affine2PieceDijkstra(c2), aln_type, device, m, qepc);
         auto align_one = [&](const graphs::POAGraph& gr, const std::string& seq, poa_stats_t* st) {
             if (two_piece) return dij ? al2_d.align_batch(gr, {seq}, true, st).at(0) : al2_m.align_batch(gr, {seq}, true, st).at(0);
             return dij ? al_d.align_batch(gr, {seq}, true, st).at(0) : al_m.align_batch(gr, {seq}, true, st).at(0);
