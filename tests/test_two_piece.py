@@ -287,3 +287,13 @@ def test_gpu_two_piece_exact_config2_sample(engine, oracle):
     assert ex(engine.Affine2PieceDijkstra, False) == 20 == int(engine.PoastaAligner(engine.Affine2PieceDijkstra(c)).align_batch(g8, q).score[0])
     assert ex(engine.Affine2PieceDijkstra, True) == 23
     assert ex(engine.Affine2PieceMinGapCost, False) == 38
+    # empty and one- / two-base queries (the backtrace's special cases, gap_affine_2piece.rs:948-965)
+    gs = W.random_dag(3, n_nodes=8, p_edge=0.3, alphabet=b"ACGT")
+    ogs = oracle.OracleGraph.from_csr(gs.as_dict())
+    short = [np.frombuffer(b, np.uint8) for b in (b"", b"A", b"AC", b"T")]
+    rs = engine.PoastaAligner(engine.Affine2PieceMinGapCost(engine.GapAffine2Piece(4, 2, 6, 1, 24)), mode="exact").align_batch(gs, short)
+    for i, q in enumerate(short):
+        with oracle.two_piece(24, 1):
+            a = ogs.astar_align(q, oracle.Costs(4, 6, 2), oracle.H_MINGAP, True)
+        assert int(rs.score[i]) == a["score"] and rs.raw_alignment(i) == a["alignment"], (bytes(q), int(rs.score[i]), a["score"])
+        assert rs.search_counters[i, :3].tolist() == [a["num_queued"], a["num_visited"], a["num_pruned"]]
