@@ -287,6 +287,10 @@ def test_gpu_two_piece_exact_config2_sample(engine, oracle):
     assert ex(engine.Affine2PieceDijkstra, False) == 20 == int(engine.PoastaAligner(engine.Affine2PieceDijkstra(c)).align_batch(g8, q).score[0])
     assert ex(engine.Affine2PieceDijkstra, True) == 23
     assert ex(engine.Affine2PieceMinGapCost, False) == 38
+    # a replay that runs out of queue workspace says so per query (POA_FLAG_EXACT_OVERFLOW) and writes nothing else
+    tiny = engine.PoastaAligner(engine.Affine2PieceMinGapCost(engine.GapAffine2Piece(4, 2, 6, 1, 24)), mode="exact", queue_entries_per_cell=1e-6)
+    ro = tiny.align_batch(g, qseq=qseq[:int(qoff[3])], qoff=qoff[:4])
+    assert all(int(f) == 0x40 for f in ro.flags) and int(ro.pair_off[3]) == 0
     # empty and one- / two-base queries (the backtrace's special cases, gap_affine_2piece.rs:948-965)
     gs = W.random_dag(3, n_nodes=8, p_edge=0.3, alphabet=b"ACGT")
     ogs = oracle.OracleGraph.from_csr(gs.as_dict())
