@@ -206,6 +206,18 @@ def test_abi_graph_validation_and_no_device_error():
         with pytest.raises(_lib.PoaError) as ei:
             al.align_batch(g, qseq=qseq, qoff=qoff)
         assert ei.value.code == -3  # POA_ERR_NO_DEVICE
+        # the two-piece entry points refuse alike, dense and replayed (no CPU search behind them either)
+        for mode in ("dense", "exact"):
+            a2 = aligner.PoastaAligner(aligner.Affine2PieceMinGapCost(aligner.GapAffine2Piece(4, 2, 6, 1, 24)), mode=mode)
+            with pytest.raises(_lib.PoaError) as ei:
+                a2.align_batch(g, qseq=qseq, qoff=qoff)
+            assert ei.value.code == -3
+    # argument checks of the two-piece entry point come before any device work: ends-free needs the replay
+    a3 = aligner.PoastaAligner(aligner.Affine2PieceMinGapCost(aligner.GapAffine2Piece(4, 2, 6, 1, 24)), aligner.AlignmentType.EndsFree(), mode="dense")
+    with pytest.raises(ValueError):
+        a3.align_batch(g, qseq=qseq, qoff=qoff)
+    with pytest.raises(ValueError):
+        aligner.GapAffine2Piece(4, 1, 6, 2, 24)   # extend1 < extend2: the reference's constructor panics (gap_affine_2piece.rs:28-33)
 
 
 def test_product_path_does_not_touch_the_oracle():
